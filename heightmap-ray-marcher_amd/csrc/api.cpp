@@ -1,0 +1,605 @@
+// api.cpp -- the C ABI declared in include/hmrm.h: scene residency in HBM,
+// per-frame host set-up + kernel launch, config and image-IO entry points.
+// There is no CPU rendering path in this library.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/hmrm.h"
+#include "config.hpp"
+#include "frame.hpp"
+#include "image_io.hpp"
+#include "render.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+thread_local double g_last_kernel_ms = -1.0;
+
+int fail(int code, const std::string &msg) {
+	g_error = msg;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+	do {                                                                                      \
+		hipError_t e_ = (expr);                                                               \
+		if (e_ != hipSuccess)                                                                 \
+			return fail(HMRM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+	} while (0)
+
+int64_t default_step_cap() {
+	// The reference loop has no cap (hmap.cpp:1000).  2^26 steps is > 2800x the
+	// longest legitimate march of the largest BASELINE config (8192*sqrt(2)/0.5).
+	const char *s = getenv("HMRM_STEP_CAP");
+	if (s && *s) {
+		long long v = atoll(s);
+		if (v > 0) return (int64_t)v;
+	}
+	return (int64_t)1 << 26;
+}
+
+} // namespace
+
+struct hmrm_scene {
+	int device = 0;
+	int32_t map_w = 0, map_h = 0;
+	hmrm_scene_params params{};
+	uint8_t *d_rgb = nullptr;   // W*H*3  base_heightmap_buf (hmap.cpp:51)
+	uint32_t *d_cmap = nullptr; // W*H    colormap_buf as packed RGBA (hmap.cpp:59)
+	double *d_thr = nullptr;    // W*H    heightmap_buf[i] + min_height
+	double thr_max = 0.0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	unsigned long long *d_counters = nullptr; // 4 x u64: steps, hits, capped, max key
+	// per-render scratch, grown on demand (a scene is used by one host thread at a time)
+	uint32_t *d_frame = nullptr;
+	size_t frame_px = 0;
+	double *d_tables = nullptr; // spherical sin/cos tables
+	double *h_tables = nullptr; // pinned staging
+	size_t tables_n = 0;
+	uint32_t *d_steps = nullptr;
+	double *d_entry = nullptr;
+	size_t stats_px = 0;
+};
+
+struct hmrm_config {
+	hmrm::Config cfg;
+	std::string log_cache, warn_cache;
+};
+
+namespace {
+
+int ensure_frame(hmrm_scene *s, size_t px) {
+	if (px <= s->frame_px) return HMRM_OK;
+	if (s->d_frame) (void)hipFree(s->d_frame);
+	s->d_frame = nullptr;
+	s->frame_px = 0;
+	HIP_TRY(hipMalloc((void **)&s->d_frame, px * sizeof(uint32_t)));
+	s->frame_px = px;
+	return HMRM_OK;
+}
+
+int ensure_tables(hmrm_scene *s, size_t n) {
+	if (n <= s->tables_n) return HMRM_OK;
+	if (s->d_tables) (void)hipFree(s->d_tables);
+	if (s->h_tables) (void)hipHostFree(s->h_tables);
+	s->d_tables = nullptr;
+	s->h_tables = nullptr;
+	s->tables_n = 0;
+	HIP_TRY(hipMalloc((void **)&s->d_tables, n * sizeof(double)));
+	HIP_TRY(hipHostMalloc((void **)&s->h_tables, n * sizeof(double), hipHostMallocDefault));
+	s->tables_n = n;
+	return HMRM_OK;
+}
+
+int ensure_stats(hmrm_scene *s, size_t px) {
+	if (px <= s->stats_px) return HMRM_OK;
+	if (s->d_steps) (void)hipFree(s->d_steps);
+	if (s->d_entry) (void)hipFree(s->d_entry);
+	s->d_steps = nullptr;
+	s->d_entry = nullptr;
+	s->stats_px = 0;
+	HIP_TRY(hipMalloc((void **)&s->d_steps, px * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **)&s->d_entry, px * sizeof(double)));
+	s->stats_px = px;
+	return HMRM_OK;
+}
+
+int check_camera(const hmrm_camera *cam) {
+	if (!cam) return fail(HMRM_E_ARG, "camera is NULL");
+	if (cam->width <= 0 || cam->height <= 0) return fail(HMRM_E_ARG, "resolution must be positive");
+	if ((int64_t)cam->width * cam->height > ((int64_t)1 << 31) / 4)
+		return fail(HMRM_E_ARG, "resolution too large (the reference indexes the framebuffer with int)");
+	if (cam->projection < 1 || cam->projection > 3) return fail(HMRM_E_ARG, "projection must be 1, 2 or 3");
+	return HMRM_OK;
+}
+
+// Host set-up for one frame: fills `f` and, for spherical, enqueues the table upload.
+int prepare_frame(hmrm_scene *s, const hmrm_camera *cam, hipStream_t stream, hmrm::DevFrame *f) {
+	hmrm::HostCamera hc{};
+	hc.width = cam->width;
+	hc.height = cam->height;
+	hc.projection = cam->projection;
+	hc.bg_r = cam->bg_r;
+	hc.bg_g = cam->bg_g;
+	hc.bg_b = cam->bg_b;
+	hc.hfov = cam->hfov;
+	hc.hang = cam->hang;
+	hc.vang = cam->vang;
+	hc.pos[0] = cam->pos[0];
+	hc.pos[1] = cam->pos[1];
+	hc.pos[2] = cam->pos[2];
+	hc.ortho_width = cam->ortho_width;
+	hc.step_dist = cam->step_dist;
+	double *cc = nullptr, *cs = nullptr, *rs = nullptr, *rc = nullptr;
+	const size_t W = (size_t)cam->width, H = (size_t)cam->height;
+	if (cam->projection == HMRM_SPHERICAL) {
+		int rc_ = ensure_tables(s, 2 * W + 2 * H);
+		if (rc_) return rc_;
+		cc = s->h_tables;
+		cs = cc + W;
+		rs = cs + W;
+		rc = rs + H;
+	}
+	hmrm::build_frame(hc, s->map_w, s->map_h, s->params.min_height, s->params.max_height,
+	                  s->params.grid_width, f, cc, cs, rs, rc);
+	if (cam->projection == HMRM_SPHERICAL) {
+		HIP_TRY(hipMemcpyAsync(s->d_tables, s->h_tables, (2 * W + 2 * H) * sizeof(double),
+		                       hipMemcpyHostToDevice, stream));
+		f->col_cos_ha = s->d_tables;
+		f->col_sin_ha = s->d_tables + W;
+		f->row_sin_va = s->d_tables + 2 * W;
+		f->row_cos_va = s->d_tables + 2 * W + H;
+	}
+	f->thr_max = s->thr_max;
+	f->step_cap = default_step_cap();
+	return HMRM_OK;
+}
+
+int run_update_heights(hmrm_scene *s) {
+	const int64_t n = (int64_t)s->map_w * s->map_h;
+	HIP_TRY(hipMemsetAsync(s->d_counters + 3, 0, sizeof(unsigned long long), s->stream));
+	HIP_TRY(hmrm::launch_prepare_heights(s->d_rgb, s->d_thr, n, s->params.lum_r, s->params.lum_g,
+	                                     s->params.lum_b, s->params.min_height, s->params.max_height,
+	                                     false, s->d_counters + 3, s->stream));
+	unsigned long long key = 0;
+	HIP_TRY(hipMemcpyAsync(&key, s->d_counters + 3, sizeof key, hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	s->thr_max = key ? hmrm::max_key_to_double(key) : -__builtin_huge_val();
+	return HMRM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int hmrm_abi_version(void) { return HMRM_ABI_VERSION; }
+const char *hmrm_last_error(void) { return g_error.c_str(); }
+
+int hmrm_device_count(void) {
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) return fail(HMRM_E_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+	return n;
+}
+
+int hmrm_set_device(int device) {
+	HIP_TRY(hipSetDevice(device));
+	return HMRM_OK;
+}
+
+int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int32_t map_w,
+                      int32_t map_h, const hmrm_scene_params *params, hmrm_scene **out) {
+	if (!height_rgb || !color_rgba || !params || !out) return fail(HMRM_E_ARG, "NULL argument");
+	if (map_w <= 0 || map_h <= 0) return fail(HMRM_E_ARG, "map dimensions must be positive");
+	// the reference indexes (gridx + gridy*W)*4 with int (hmap.cpp:1018)
+	if ((int64_t)map_w * map_h > ((int64_t)1 << 31) / 4)
+		return fail(HMRM_E_ARG, "map too large (the reference indexes the colormap with int)");
+	*out = nullptr;
+	hmrm_scene *s = new (std::nothrow) hmrm_scene();
+	if (!s) return fail(HMRM_E_ARG, "out of memory");
+	const size_t n = (size_t)map_w * (size_t)map_h;
+	s->map_w = map_w;
+	s->map_h = map_h;
+	s->params = *params;
+	int rc = HMRM_OK;
+	auto body = [&]() -> int {
+		HIP_TRY(hipGetDevice(&s->device));
+		HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreate(&s->ev0));
+		HIP_TRY(hipEventCreate(&s->ev1));
+		HIP_TRY(hipMalloc((void **)&s->d_rgb, n * 3));
+		HIP_TRY(hipMalloc((void **)&s->d_cmap, n * 4));
+		HIP_TRY(hipMalloc((void **)&s->d_thr, n * sizeof(double)));
+		HIP_TRY(hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned long long)));
+		HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), s->stream));
+		HIP_TRY(hipMemcpyAsync(s->d_rgb, height_rgb, n * 3, hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->d_cmap, color_rgba, n * 4, hipMemcpyHostToDevice, s->stream));
+		return run_update_heights(s);
+	};
+	rc = body();
+	if (rc != HMRM_OK) {
+		std::string keep = g_error;
+		hmrm_scene_destroy(s);
+		g_error = keep;
+		return rc;
+	}
+	*out = s;
+	return HMRM_OK;
+}
+
+int hmrm_scene_update(hmrm_scene *s, const hmrm_scene_params *params) {
+	if (!s || !params) return fail(HMRM_E_ARG, "NULL argument");
+	HIP_TRY(hipSetDevice(s->device));
+	s->params = *params;
+	return run_update_heights(s);
+}
+
+void hmrm_scene_destroy(hmrm_scene *s) {
+	if (!s) return;
+	(void)hipSetDevice(s->device);
+	if (s->stream) (void)hipStreamSynchronize(s->stream);
+	if (s->d_rgb) (void)hipFree(s->d_rgb);
+	if (s->d_cmap) (void)hipFree(s->d_cmap);
+	if (s->d_thr) (void)hipFree(s->d_thr);
+	if (s->d_counters) (void)hipFree(s->d_counters);
+	if (s->d_frame) (void)hipFree(s->d_frame);
+	if (s->d_tables) (void)hipFree(s->d_tables);
+	if (s->h_tables) (void)hipHostFree(s->h_tables);
+	if (s->d_steps) (void)hipFree(s->d_steps);
+	if (s->d_entry) (void)hipFree(s->d_entry);
+	if (s->ev0) (void)hipEventDestroy(s->ev0);
+	if (s->ev1) (void)hipEventDestroy(s->ev1);
+	if (s->stream) (void)hipStreamDestroy(s->stream);
+	delete s;
+}
+
+int hmrm_scene_read_heights(const hmrm_scene *cs, double *out) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(cs);
+	if (!s || !out) return fail(HMRM_E_ARG, "NULL argument");
+	HIP_TRY(hipSetDevice(s->device));
+	const int64_t n = (int64_t)s->map_w * s->map_h;
+	double *tmp = nullptr;
+	HIP_TRY(hipMalloc((void **)&tmp, (size_t)n * sizeof(double)));
+	hipError_t e = hmrm::launch_prepare_heights(s->d_rgb, tmp, n, s->params.lum_r, s->params.lum_g,
+	                                            s->params.lum_b, s->params.min_height,
+	                                            s->params.max_height, true, nullptr, s->stream);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(out, tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+	(void)hipFree(tmp);
+	if (e != hipSuccess) return fail(HMRM_E_DEVICE, std::string("read_heights: ") + hipGetErrorString(e));
+	return HMRM_OK;
+}
+
+static int render_common(hmrm_scene *s, const hmrm_camera *cam, uint8_t *rgba, size_t stride_bytes,
+                         hmrm_stats *stats, uint32_t *steps_pp, double *entry_d, bool want_stats) {
+	int rc = check_camera(cam);
+	if (rc) return rc;
+	if (!s || !rgba) return fail(HMRM_E_ARG, "NULL argument");
+	const size_t W = (size_t)cam->width, H = (size_t)cam->height;
+	if (stride_bytes < W * 4) return fail(HMRM_E_ARG, "stride_bytes < width*4");
+	HIP_TRY(hipSetDevice(s->device));
+	if ((rc = ensure_frame(s, W * H))) return rc;
+	if (want_stats && (rc = ensure_stats(s, W * H))) return rc;
+	hmrm::DevFrame f;
+	if ((rc = prepare_frame(s, cam, s->stream, &f))) return rc;
+	hmrm::RowMap rows{0, cam->height, 0, 0, 1};
+	HIP_TRY(hipMemsetAsync(s->d_counters, 0, 3 * sizeof(unsigned long long), s->stream));
+	HIP_TRY(hipEventRecord(s->ev0, s->stream));
+	HIP_TRY(hmrm::launch_render(f, rows, s->d_thr, s->d_cmap, s->d_frame, (int64_t)W, s->d_counters,
+	                            want_stats ? s->d_steps : nullptr, want_stats ? s->d_entry : nullptr,
+	                            want_stats, s->stream));
+	HIP_TRY(hipEventRecord(s->ev1, s->stream));
+	HIP_TRY(hipMemcpy2DAsync(rgba, stride_bytes, s->d_frame, W * 4, W * 4, H, hipMemcpyDeviceToHost,
+	                         s->stream));
+	unsigned long long counters[3] = {0, 0, 0};
+	HIP_TRY(hipMemcpyAsync(counters, s->d_counters, sizeof counters, hipMemcpyDeviceToHost, s->stream));
+	if (want_stats && steps_pp)
+		HIP_TRY(hipMemcpyAsync(steps_pp, s->d_steps, W * H * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+	if (want_stats && entry_d)
+		HIP_TRY(hipMemcpyAsync(entry_d, s->d_entry, W * H * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	float ms = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+	g_last_kernel_ms = ms;
+	if (stats) {
+		stats->rays = (uint64_t)W * H;
+		stats->steps = counters[0];
+		stats->hits = counters[1];
+		stats->capped = counters[2];
+	}
+	if (counters[2]) {
+		char buf[160];
+		snprintf(buf, sizeof buf,
+		         "%llu ray(s) reached the step cap; the reference's loop would not terminate for them",
+		         counters[2]);
+		return fail(HMRM_E_NOTERM, buf);
+	}
+	return HMRM_OK;
+}
+
+int hmrm_render(const hmrm_scene *scene, const hmrm_camera *cam, uint8_t *rgba, size_t stride_bytes) {
+	return render_common(const_cast<hmrm_scene *>(scene), cam, rgba, stride_bytes, nullptr, nullptr,
+	                     nullptr, false);
+}
+
+int hmrm_render_stats(const hmrm_scene *scene, const hmrm_camera *cam, uint8_t *rgba,
+                      size_t stride_bytes, hmrm_stats *stats, uint32_t *steps_per_pixel, double *entry_d) {
+	return render_common(const_cast<hmrm_scene *>(scene), cam, rgba, stride_bytes, stats,
+	                     steps_per_pixel, entry_d, true);
+}
+
+int hmrm_render_rows_device(const hmrm_scene *scene, const hmrm_camera *cam, void *d_rgba,
+                            size_t stride_bytes, int32_t row_begin, int32_t row_end, int32_t band_rows,
+                            int32_t band_index, int32_t band_count, void *hip_stream) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
+	int rc = check_camera(cam);
+	if (rc) return rc;
+	if (!s || !d_rgba) return fail(HMRM_E_ARG, "NULL argument");
+	if (stride_bytes < (size_t)cam->width * 4 || (stride_bytes & 3))
+		return fail(HMRM_E_ARG, "stride_bytes must be >= width*4 and a multiple of 4");
+	hmrm::RowMap rows{};
+	if (band_rows > 0) {
+		if (band_count <= 0 || band_index < 0 || band_index >= band_count)
+			return fail(HMRM_E_ARG, "bad band_index/band_count");
+		// bands band_index, band_index+band_count, ... packed back to back; a trailing
+		// partial band still occupies band_rows rows of the strip (its tail is not written)
+		const int64_t local = hmrm_band_local_rows(cam->height, band_rows, band_index, band_count);
+		rows.row_begin = 0;
+		rows.local_rows = (int32_t)local;
+		rows.band_rows = band_rows;
+		rows.band_index = band_index;
+		rows.band_count = band_count;
+	} else {
+		if (row_begin < 0 || row_end > cam->height || row_begin > row_end)
+			return fail(HMRM_E_ARG, "bad row range");
+		rows.row_begin = row_begin;
+		rows.local_rows = row_end - row_begin;
+		rows.band_rows = 0;
+		rows.band_index = 0;
+		rows.band_count = 1;
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	hipStream_t stream = (hipStream_t)hip_stream;
+	hmrm::DevFrame f;
+	if ((rc = prepare_frame(s, cam, stream, &f))) return rc;
+	HIP_TRY(hmrm::launch_render(f, rows, s->d_thr, s->d_cmap, (uint32_t *)d_rgba,
+	                            (int64_t)(stride_bytes / 4), s->d_counters, nullptr, nullptr, false, stream));
+	return HMRM_OK;
+}
+
+double hmrm_last_kernel_ms(void) { return g_last_kernel_ms; }
+
+double hmrm_bench_kernel_ms(const hmrm_scene *scene, const hmrm_camera *cam, int32_t iters) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
+	if (check_camera(cam) || !s || iters <= 0) {
+		if (g_error.empty()) g_error = "bad argument";
+		return -1.0;
+	}
+	auto body = [&]() -> int {
+		const size_t W = (size_t)cam->width, H = (size_t)cam->height;
+		HIP_TRY(hipSetDevice(s->device));
+		int rc = ensure_frame(s, W * H);
+		if (rc) return rc;
+		hmrm::DevFrame f;
+		if ((rc = prepare_frame(s, cam, s->stream, &f))) return rc;
+		hmrm::RowMap rows{0, cam->height, 0, 0, 1};
+		HIP_TRY(hipEventRecord(s->ev0, s->stream));
+		for (int i = 0; i < iters; ++i)
+			HIP_TRY(hmrm::launch_render(f, rows, s->d_thr, s->d_cmap, s->d_frame, (int64_t)W,
+			                            s->d_counters, nullptr, nullptr, false, s->stream));
+		HIP_TRY(hipEventRecord(s->ev1, s->stream));
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		float ms = 0.f;
+		HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+		g_last_kernel_ms = ms / iters;
+		return HMRM_OK;
+	};
+	if (body() != HMRM_OK) return -1.0;
+	return g_last_kernel_ms;
+}
+
+// ------------------------------------------------------------------ config --
+hmrm_config *hmrm_config_create(void) { return new (std::nothrow) hmrm_config(); }
+void hmrm_config_destroy(hmrm_config *c) { delete c; }
+
+int hmrm_config_consume_file(hmrm_config *c, const char *path) {
+	if (!c || !path) return fail(HMRM_E_ARG, "NULL argument");
+	std::ifstream in(path);
+	if (!in.is_open()) return fail(HMRM_E_IO, std::string("Failed to open input file: ") + path); // hmap.cpp:537-540
+	std::string fatal;
+	if (!c->cfg.consume(in, &fatal)) {
+		bool img = fatal.compare(0, 14, "Failed to load") == 0;
+		return fail(img ? HMRM_E_IMAGE : HMRM_E_CONFIG, fatal);
+	}
+	return HMRM_OK;
+}
+
+int hmrm_config_consume_string(hmrm_config *c, const char *text) {
+	if (!c || !text) return fail(HMRM_E_ARG, "NULL argument");
+	std::istringstream in(text);
+	std::string fatal;
+	if (!c->cfg.consume(in, &fatal)) {
+		bool img = fatal.compare(0, 14, "Failed to load") == 0;
+		return fail(img ? HMRM_E_IMAGE : HMRM_E_CONFIG, fatal);
+	}
+	return HMRM_OK;
+}
+
+const char *hmrm_config_log(const hmrm_config *c) {
+	hmrm_config *m = const_cast<hmrm_config *>(c);
+	m->log_cache = m->cfg.log.str();
+	return m->log_cache.c_str();
+}
+const char *hmrm_config_warnings(const hmrm_config *c) {
+	hmrm_config *m = const_cast<hmrm_config *>(c);
+	m->warn_cache = m->cfg.warn.str();
+	return m->warn_cache.c_str();
+}
+
+void hmrm_config_get_camera(const hmrm_config *c, hmrm_camera *out) {
+	const hmrm::Config &g = c->cfg;
+	memset(out, 0, sizeof *out);
+	out->width = g.screen_width;
+	out->height = g.screen_height;
+	out->projection = g.image_plane;
+	out->bg_r = g.bg_r;
+	out->bg_g = g.bg_g;
+	out->bg_b = g.bg_b;
+	out->hfov = g.hfov;
+	out->hang = g.hang;
+	out->vang = g.vang;
+	out->pos[0] = g.cam_pos[0];
+	out->pos[1] = g.cam_pos[1];
+	out->pos[2] = g.cam_pos[2];
+	out->ortho_width = g.ortho_width;
+	out->step_dist = g.step_dist;
+}
+
+void hmrm_config_get_scene_params(const hmrm_config *c, hmrm_scene_params *out) {
+	const hmrm::Config &g = c->cfg;
+	out->min_height = g.min_height;
+	out->max_height = g.max_height;
+	out->lum_r = g.lum_r;
+	out->lum_g = g.lum_g;
+	out->lum_b = g.lum_b;
+	out->grid_width = g.grid_width;
+}
+
+int32_t hmrm_config_cycle(const hmrm_config *c) { return c->cfg.cycle_period; }
+int32_t hmrm_config_recording_frame_count(const hmrm_config *c) { return c->cfg.recording_frame_count; }
+const char *hmrm_config_heightmap_path(const hmrm_config *c) { return c->cfg.heightmap_path.c_str(); }
+const char *hmrm_config_colormap_path(const hmrm_config *c) { return c->cfg.colormap_path.c_str(); }
+const char *hmrm_config_output_path(const hmrm_config *c) { return c->cfg.output_path.c_str(); }
+
+const uint8_t *hmrm_config_height_rgb(const hmrm_config *c, int32_t *w, int32_t *h) {
+	if (!c->cfg.have_heightmap) return nullptr;
+	if (w) *w = c->cfg.heightmap.w;
+	if (h) *h = c->cfg.heightmap.h;
+	return c->cfg.heightmap.px.data();
+}
+const uint8_t *hmrm_config_color_rgba(const hmrm_config *c, int32_t *w, int32_t *h) {
+	if (!c->cfg.have_colormap) return nullptr;
+	if (w) *w = c->cfg.colormap.w;
+	if (h) *h = c->cfg.colormap.h;
+	return c->cfg.colormap.px.data();
+}
+int hmrm_config_take_heightmap_dirty(hmrm_config *c) {
+	int d = c->cfg.heightmap_dirty ? 1 : 0;
+	c->cfg.heightmap_dirty = false;
+	return d;
+}
+int hmrm_config_create_scene(const hmrm_config *c, hmrm_scene **out) {
+	if (!c || !out) return fail(HMRM_E_ARG, "NULL argument");
+	if (!c->cfg.have_heightmap) return fail(HMRM_E_CONFIG, "Must specify heightmap in config");
+	if (!c->cfg.have_colormap) return fail(HMRM_E_CONFIG, "Must specify colormap in config");
+	hmrm_scene_params p;
+	hmrm_config_get_scene_params(c, &p);
+	return hmrm_scene_create(c->cfg.heightmap.px.data(), c->cfg.colormap.px.data(), c->cfg.heightmap.w,
+	                         c->cfg.heightmap.h, &p, out);
+}
+
+// ---------------------------------------------------------------- image IO --
+static int hand_out(hmrm::Image &img, uint8_t **out, int32_t *w, int32_t *h, int32_t *n) {
+	uint8_t *p = (uint8_t *)malloc(img.px.size() ? img.px.size() : 1);
+	if (!p) return fail(HMRM_E_ARG, "out of memory");
+	memcpy(p, img.px.data(), img.px.size());
+	*out = p;
+	if (w) *w = img.w;
+	if (h) *h = img.h;
+	if (n) *n = img.comp_in_file;
+	return HMRM_OK;
+}
+
+int hmrm_image_load(const char *path, int32_t req_comp, uint8_t **out, int32_t *w, int32_t *h,
+                    int32_t *comp_in_file) {
+	if (!path || !out) return fail(HMRM_E_ARG, "NULL argument");
+	hmrm::Image img;
+	std::string err;
+	if (!hmrm::load_image_file(path, req_comp, &img, &err))
+		return fail(err == "can't fopen" ? HMRM_E_IO : HMRM_E_IMAGE, err);
+	return hand_out(img, out, w, h, comp_in_file);
+}
+
+int hmrm_image_load_memory(const uint8_t *bytes, size_t len, int32_t req_comp, uint8_t **out,
+                           int32_t *w, int32_t *h, int32_t *comp_in_file) {
+	if (!bytes || !out) return fail(HMRM_E_ARG, "NULL argument");
+	hmrm::Image img;
+	std::string err;
+	if (!hmrm::decode_image(bytes, len, req_comp, &img, &err)) return fail(HMRM_E_IMAGE, err);
+	return hand_out(img, out, w, h, comp_in_file);
+}
+
+void hmrm_image_free(void *p) { free(p); }
+
+int hmrm_write_png_memory(int32_t w, int32_t h, int32_t comp, const uint8_t *data, size_t stride_bytes,
+                          uint8_t **out, size_t *out_len) {
+	if (!out || !out_len) return fail(HMRM_E_ARG, "NULL argument");
+	std::vector<uint8_t> png;
+	if (!hmrm::encode_png(w, h, comp, data, stride_bytes, &png)) return fail(HMRM_E_ARG, "bad image arguments");
+	uint8_t *p = (uint8_t *)malloc(png.size());
+	if (!p) return fail(HMRM_E_ARG, "out of memory");
+	memcpy(p, png.data(), png.size());
+	*out = p;
+	*out_len = png.size();
+	return HMRM_OK;
+}
+
+int hmrm_write_png(const char *path, int32_t w, int32_t h, int32_t comp, const uint8_t *data,
+                   size_t stride_bytes) {
+	if (!path) return fail(HMRM_E_ARG, "NULL argument");
+	std::vector<uint8_t> png;
+	if (!hmrm::encode_png(w, h, comp, data, stride_bytes, &png)) return fail(HMRM_E_ARG, "bad image arguments");
+	if (!hmrm::write_file(path, png.data(), png.size()))
+		return fail(HMRM_E_IO, std::string("Failed to write screenshot to ") + path); // hmap.cpp:162-164
+	return HMRM_OK;
+}
+
+int hmrm_write_ppm(const char *path, int32_t w, int32_t h, int32_t comp, const uint8_t *data,
+                   size_t stride_bytes) {
+	if (!path) return fail(HMRM_E_ARG, "NULL argument");
+	std::vector<uint8_t> pnm;
+	if (!hmrm::encode_pnm(w, h, comp, data, stride_bytes, &pnm)) return fail(HMRM_E_ARG, "bad image arguments");
+	if (!hmrm::write_file(path, pnm.data(), pnm.size()))
+		return fail(HMRM_E_IO, std::string("Failed to write image to ") + path);
+	return HMRM_OK;
+}
+
+// Device-side GetRay + distance() for one pixel (test hook).
+int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam, int32_t px, int32_t py,
+                   double pos[3], double dir[3], double *entry_d) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
+	int rc = check_camera(cam);
+	if (rc) return rc;
+	if (!s || !pos || !dir || !entry_d) return fail(HMRM_E_ARG, "NULL argument");
+	if (px < 0 || py < 0 || px >= cam->width || py >= cam->height) return fail(HMRM_E_ARG, "pixel out of range");
+	HIP_TRY(hipSetDevice(s->device));
+	if ((rc = ensure_stats(s, 8))) return rc;
+	hmrm::DevFrame f;
+	if ((rc = prepare_frame(s, cam, s->stream, &f))) return rc;
+	HIP_TRY(hmrm::launch_probe(f, px, py, s->d_entry, s->stream));
+	double host[7];
+	HIP_TRY(hipMemcpyAsync(host, s->d_entry, sizeof host, hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	for (int i = 0; i < 3; ++i) { pos[i] = host[i]; dir[i] = host[3 + i]; }
+	*entry_d = host[6];
+	return HMRM_OK;
+}
+
+int32_t hmrm_band_local_rows(int32_t height, int32_t band_rows, int32_t band_index, int32_t band_count) {
+	if (height <= 0 || band_rows <= 0 || band_count <= 0 || band_index < 0 || band_index >= band_count) return 0;
+	int64_t local = 0;
+	for (int64_t b = band_index; b * band_rows < height; b += band_count) local += band_rows;
+	return (int32_t)local;
+}
+
+} // extern "C"

@@ -1,0 +1,142 @@
+// camera.cpp -- per-frame host set-up: camera basis, image plane, box corners.
+//
+// Mirrors what the reference does on the host once per frame
+// (main/hmap.cpp:661-672 look/up; :952-965 ImagePlane construction =
+// src/Perspective.cpp:3-23, src/Spherical.cpp:3-15, src/Orthographic.cpp:3-17;
+// :968-974 hmap_c0/hmap_c1).  All libm calls (sin, cos, tan) stay on the host so
+// they are glibc's, as in the reference; the device never evaluates a
+// transcendental.  Must be compiled with -ffp-contract=off -fno-builtin and
+// without -ffast-math: the value of every expression below is part of the
+// pixel-exactness contract.
+//
+// glm semantics (glm 0.9.9.8, not vendored by the reference) are restated in
+// Vec3's operators: component-wise +,-; s*v; cross; dot = (x+y)+z;
+// normalize = v * (1/sqrt(dot(v,v))).
+#include "frame.hpp"
+
+#include <cmath>
+
+namespace hmrm {
+namespace {
+
+struct Vec3 {
+	double x, y, z;
+};
+inline Vec3 operator+(Vec3 a, Vec3 b) { return Vec3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec3 operator-(Vec3 a, Vec3 b) { return Vec3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 operator-(Vec3 a) { return Vec3{-a.x, -a.y, -a.z}; }
+inline Vec3 operator*(double s, Vec3 v) { return Vec3{s * v.x, s * v.y, s * v.z}; }
+inline Vec3 cross(Vec3 a, Vec3 b) {
+	return Vec3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+inline double dot(Vec3 a, Vec3 b) {
+	const double px = a.x * b.x, py = a.y * b.y, pz = a.z * b.z;
+	return px + py + pz;
+}
+inline Vec3 normalize(Vec3 v) {
+	const double inv = 1.0 / std::sqrt(dot(v, v));
+	return Vec3{v.x * inv, v.y * inv, v.z * inv};
+}
+// Orthographic's constructor takes look/up as glm::vec3 (float) by value
+// (src/Orthographic.cpp:3) although the caller holds dvec3 (hmap.cpp:963).
+inline Vec3 through_float(Vec3 v) {
+	return Vec3{(double)(float)v.x, (double)(float)v.y, (double)(float)v.z};
+}
+inline void store(double dst[3], Vec3 v) {
+	dst[0] = v.x;
+	dst[1] = v.y;
+	dst[2] = v.z;
+}
+
+} // namespace
+
+void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min_height,
+                 double max_height, double grid_width, DevFrame *f, double *col_cos_ha,
+                 double *col_sin_ha, double *row_sin_va, double *row_cos_va) {
+	*f = DevFrame();
+	f->screen_w = cam.width;
+	f->screen_h = cam.height;
+	f->projection = cam.projection;
+	f->map_w = map_w;
+	f->map_h = map_h;
+	f->bg[0] = cam.bg_r;
+	f->bg[1] = cam.bg_g;
+	f->bg[2] = cam.bg_b;
+	f->bg[3] = 255;
+
+	const Vec3 pos{cam.pos[0], cam.pos[1], cam.pos[2]};
+	store(f->cam, pos);
+
+	// hmap.cpp:661-672
+	const double hang = cam.hang, vang = cam.vang;
+	const Vec3 look{std::sin(vang) * std::cos(hang), std::sin(vang) * std::sin(hang), std::cos(vang)};
+	const double up_vang = vang - (M_PI / 2.0);
+	const Vec3 up{std::sin(up_vang) * std::cos(hang), std::sin(up_vang) * std::sin(hang),
+	              std::cos(up_vang)};
+
+	const double aspect = (double)cam.width / cam.height; // hmap.cpp:955-956
+
+	if (cam.projection == 1) {
+		// src/Perspective.cpp:10-22
+		const double half_w = std::tan(cam.hfov / 2.0);
+		const double half_h = half_w / aspect;
+		const Vec3 right = normalize(cross(look, up));
+		const Vec3 centre = pos + look;
+		const Vec3 ul = (centre + half_h * up) - half_w * right;
+		const Vec3 ll = (centre - half_h * up) - half_w * right;
+		const Vec3 ur = (centre + half_h * up) + half_w * right;
+		store(f->upper_left, ul);
+		store(f->plane_right, ur - ul);
+		store(f->plane_down, ll - ul);
+	} else if (cam.projection == 2) {
+		// src/Spherical.cpp:11-14, then the separable halves of :18-25
+		const double hfov = cam.hfov;
+		const double vfov = hfov / aspect;
+		const double ul_hang = hang + (hfov / 2.0);
+		const double ul_vang = vang - (vfov / 2.0);
+		for (int32_t px = 0; px < cam.width; ++px) {
+			const double w = (double)px / (cam.width - 1); // hmap.cpp:986
+			const double ha = ul_hang - w * hfov;
+			col_cos_ha[px] = std::cos(ha);
+			col_sin_ha[px] = std::sin(ha);
+		}
+		for (int32_t py = 0; py < cam.height; ++py) {
+			const double h = (double)py / (cam.height - 1); // hmap.cpp:987
+			const double va = ul_vang + h * vfov;
+			row_sin_va[py] = std::sin(va);
+			row_cos_va[py] = std::cos(va);
+		}
+	} else {
+		// src/Orthographic.cpp:5-16
+		const Vec3 lk = through_float(look);
+		const Vec3 u = through_float(up);
+		const Vec3 right = cross(lk, u);
+		const double ow = cam.ortho_width;
+		const Vec3 ul = (pos - ((cam.width / 2.0) * ow) * right) + ((cam.height / 2.0) * ow) * u;
+		store(f->look, lk);
+		store(f->upper_left, ul);
+		store(f->plane_right, (cam.width * ow) * right);
+		store(f->plane_down, (cam.height * ow) * (-u));
+	}
+
+	// hmap.cpp:968-974
+	f->c0[0] = 0.0;
+	f->c0[1] = 0.0;
+	f->c0[2] = min_height;
+	f->c1[0] = f->c0[0] + map_w * grid_width;
+	f->c1[1] = f->c0[1] - map_h * grid_width;
+	f->c1[2] = max_height;
+
+	f->grid_width = grid_width;
+	f->nudge = grid_width * 0.01; // hmap.cpp:998
+	f->step_dist = cam.step_dist;
+
+	// x / 2^k == x * 2^-k bit for bit (both are the correctly rounded value of the
+	// same real number) as long as 2^-k is representable: normal power of two.
+	int e = 0;
+	const double m = std::frexp(grid_width, &e);
+	f->grid_pow2 = (std::isfinite(grid_width) && m == 0.5 && e > -1000 && e < 1000) ? 1 : 0;
+	f->inv_grid_width = f->grid_pow2 ? 1.0 / grid_width : 0.0;
+}
+
+} // namespace hmrm

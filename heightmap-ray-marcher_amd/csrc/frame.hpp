@@ -1,0 +1,67 @@
+// frame.hpp -- the per-frame record the host hands to the render kernel.
+//
+// The reference rebuilds an ImagePlane object and the two box corners every
+// frame on the host (main/hmap.cpp:661-672, :952-974) and the pixel loop reads
+// them.  Here the same quantities are computed once per frame on the host (with
+// glibc's sin/cos/tan, so the bits match the reference's libm calls) and passed
+// BY VALUE as a kernel argument: they live in SGPRs / the scalar cache, no
+// per-pixel memory traffic.
+#pragma once
+#include <stdint.h>
+
+namespace hmrm {
+
+struct DevFrame {
+	// framebuffer (main/hmap.cpp:31-32)
+	int32_t screen_w, screen_h;
+	int32_t projection;          // 1 perspective, 2 spherical, 3 orthographic (:104-106)
+	// heightmap / colormap dimensions (:54-55,:60-61; equal by :503-515)
+	int32_t map_w, map_h;
+	uint8_t bg[4];               // bg_r,bg_g,bg_b,255 (:110-112)
+	// Ray origin for perspective/spherical = cam_pos (Perspective.cpp:26, Spherical.cpp:21)
+	double cam[3];
+	// Perspective.cpp:16-22 / Orthographic.cpp:13-16
+	double upper_left[3], plane_right[3], plane_down[3];
+	// Orthographic.cpp:5 (float-rounded look), used as ray.dir
+	double look[3];
+	// Spherical.cpp:23-25 is separable: sin/cos(va) depend on the row only,
+	// sin/cos(ha) on the column only.  Host-built tables (glibc), device memory.
+	const double *col_cos_ha, *col_sin_ha;   // screen_w entries
+	const double *row_sin_va, *row_cos_va;   // screen_h entries
+	// box corners (hmap.cpp:968-974)
+	double c0[3], c1[3];
+	double grid_width;           // :65
+	double nudge;                // grid_width * 0.01 (:998)
+	double step_dist;            // :68
+	// ---- derived, bit-preserving helpers (not in the reference) ----
+	double inv_grid_width;       // 1/grid_width, only used when grid_pow2 != 0
+	int32_t grid_pow2;           // grid_width is a normal power of two: x/gw == x*(1/gw) exactly
+	int32_t pad_;
+	double thr_max;              // max over cells of heightmap_buf[i] + c0.z
+	int64_t step_cap;            // guard for the reference's unbounded while(true) (:1000)
+};
+
+// Which framebuffer rows a launch covers and where they land in the output.
+struct RowMap {
+	int32_t row_begin;     // contiguous mode: first global row
+	int32_t local_rows;    // rows held by the output buffer
+	int32_t band_rows;     // 0 = contiguous; else cyclic bands of this many rows
+	int32_t band_index, band_count;
+};
+
+// Host: fill everything except the table pointers / thr_max / step_cap.
+// Also fills the spherical tables (host arrays of screen_w / screen_h doubles) when
+// projection == 2.  Returns false on invalid arguments.
+struct HostCamera {
+	int32_t width, height, projection;
+	uint8_t bg_r, bg_g, bg_b;
+	double hfov, hang, vang, pos[3], ortho_width, step_dist;
+};
+
+void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h,
+                 double min_height, double max_height, double grid_width,
+                 DevFrame *out,
+                 double *col_cos_ha, double *col_sin_ha,   // width entries each (spherical) or null
+                 double *row_sin_va, double *row_cos_va);  // height entries each (spherical) or null
+
+} // namespace hmrm

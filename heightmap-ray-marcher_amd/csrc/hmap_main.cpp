@@ -1,0 +1,86 @@
+// hmap -- headless command line front end over libhmrm's C ABI.
+//
+// Same argv contract as the reference (main/hmap.cpp:526-544): exactly one
+// argument, the config file; "USAGE" + exit 1 otherwise; every parsed option is
+// echoed to stdout; warnings/errors go to stderr; fatal conditions exit 1.
+// Instead of opening an SDL window (hmap.cpp:546-649, out of scope) it renders
+// ONE full frame (`cycle 1` semantics) on the GPU and saves it the way F12 does
+// (hmap.cpp:828-850 -> SavePNG :157-168): to the config's `output` path if
+// given (.ppm selects binary PPM), else screenshots/hmap_<epoch>.png.
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/hmrm.h"
+
+static bool ends_with(const std::string &s, const char *suffix) {
+	const size_t n = strlen(suffix);
+	return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+int main(int argc, char *argv[]) {
+	if (argc != 2) {
+		std::cerr << "USAGE: hmap.exe path/to/config.txt\n";
+		return 1;
+	}
+	hmrm_config *cfg = hmrm_config_create();
+	int rc = hmrm_config_consume_file(cfg, argv[1]);
+	std::cout << hmrm_config_log(cfg);
+	std::cerr << hmrm_config_warnings(cfg);
+	if (rc != HMRM_OK) {
+		if (rc == HMRM_E_IO) std::cerr << hmrm_last_error() << "\n";
+		return 1;
+	}
+
+	hmrm_camera cam;
+	hmrm_config_get_camera(cfg, &cam);
+	hmrm_scene *scene = NULL;
+	if (hmrm_config_create_scene(cfg, &scene) != HMRM_OK) {
+		std::cerr << hmrm_last_error() << "\n";
+		return 1;
+	}
+
+	std::vector<uint8_t> framebuf((size_t)cam.width * cam.height * 4);
+	hmrm_stats stats;
+	rc = hmrm_render_stats(scene, &cam, framebuf.data(), (size_t)cam.width * 4, &stats, NULL, NULL);
+	if (rc != HMRM_OK && rc != HMRM_E_NOTERM) {
+		std::cerr << hmrm_last_error() << "\n";
+		return 1;
+	}
+	if (rc == HMRM_E_NOTERM) std::cerr << "WARNING: " << hmrm_last_error() << "\n";
+	std::cout << "rendered " << stats.rays << " rays, " << stats.steps << " ray-steps, " << stats.hits
+	          << " hits in " << hmrm_last_kernel_ms() << " ms (kernel)\n";
+
+	std::string path = hmrm_config_output_path(cfg);
+	if (path.empty()) {
+		std::time_t seconds = std::time(NULL);
+		if (seconds == (std::time_t)(-1)) {
+			std::cerr << "Failed to get time for screenshot. Screenshot NOT saved.\n";
+			return 1;
+		}
+		mkdir("screenshots", 0777);
+		std::stringstream ss;
+		ss << "screenshots/hmap_" << seconds << ".png";
+		path = ss.str();
+	}
+	int wrc;
+	if (ends_with(path, ".ppm") || ends_with(path, ".pnm"))
+		wrc = hmrm_write_ppm(path.c_str(), cam.width, cam.height, 4, framebuf.data(), (size_t)cam.width * 4);
+	else
+		wrc = hmrm_write_png(path.c_str(), cam.width, cam.height, 4, framebuf.data(), (size_t)cam.width * 4);
+	if (wrc != HMRM_OK)
+		std::cerr << "Failed to write screenshot to " << path << "\n";
+	else
+		std::cout << "Saved screenshot at " << path << "\n";
+
+	hmrm_scene_destroy(scene);
+	hmrm_config_destroy(cfg);
+	return wrc == HMRM_OK ? 0 : 1;
+}

@@ -1,0 +1,354 @@
+// render.hip -- gfx950 kernels for the reference's hot path and their launchers.
+//
+//   k_prepare_heights  UpdateHeightmap            main/hmap.cpp:171-191
+//   k_render           the pixel loop             main/hmap.cpp:978-1058
+//                        ImagePlane::GetRay       src/{Perspective,Spherical,Orthographic}.cpp
+//                        intersection/distance    src/AABB.cpp:30-77
+//                        SetPixel                 main/hmap.cpp:139-154
+//
+// Numerical contract: every fp64 operation of the reference is performed once, in
+// the reference's order, with IEEE round-to-nearest and NO fused multiply-add
+// (this file must be compiled with -ffp-contract=off; hipcc contracts by
+// default).  Division and sqrt are the correctly rounded LLVM expansions.  No
+// transcendental is evaluated on the device (the host supplies them, frame.hpp).
+//
+// Bit-preserving departures from the literal loop, each argued where it is made:
+//   * heightmap_buf[i] + hmap_c0.z (hmap.cpp:1016) is loop invariant per cell and
+//     precomputed into the `thr` table by k_prepare_heights;
+//   * step_dist * ray.dir (hmap.cpp:1037) is loop invariant per ray and hoisted;
+//   * x / grid_width is evaluated as x * (1/grid_width) only when grid_width is a
+//     power of two (exactly representable reciprocal => identical rounding);
+//   * the (int) casts + integer range test (hmap.cpp:1001-1011) are evaluated as
+//     an fp range test followed by the cast (same predicate, no UB, NaN breaks as
+//     on x86 where cvttsd2si gives INT_MIN);
+//   * the unbounded while(true) gets a step cap that is reported, never silent.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "frame.hpp"
+#include "render.hpp"
+
+#pragma clang fp contract(off)
+
+namespace hmrm {
+
+// --------------------------------------------------------------- heights ----
+// thr[i] = heightmap_buf[i] + c0.z  with heightmap_buf[i] exactly as
+// UpdateHeightmap computes it.  PLAIN = true writes heightmap_buf[i] itself
+// (test hook).  Also reduces max(thr) with an order-preserving integer key.
+__device__ __forceinline__ unsigned long long f64_order_key(double v) {
+	unsigned long long b = (unsigned long long)__double_as_longlong(v);
+	return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void k_prepare_heights(const uint8_t *__restrict__ rgb,
+                                                         double *__restrict__ out, int64_t n,
+                                                         double lum_r, double lum_g, double lum_b,
+                                                         double min_h, double max_h,
+                                                         unsigned long long *__restrict__ max_key) {
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	unsigned long long local = 0; // smaller than the key of every double
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const double r = (double)rgb[3 * i + 0];
+		const double g = (double)rgb[3 * i + 1];
+		const double b = (double)rgb[3 * i + 2];
+		double value = ((lum_r * r) + (lum_g * g)) + (lum_b * b);
+		// Clamp<double>, hmap.cpp:118-124 (NaN falls through both tests)
+		if (value < 0.0) value = 0.0;
+		else if (value > 255.0) value = 255.0;
+		const double hz = (value / 255.0) * (max_h - min_h) + min_h;
+		const double v = PLAIN ? hz : hz + min_h; // hmap.cpp:1016: heightmap_z + hmap_c0.z
+		out[i] = v;
+		if (!PLAIN) {
+			const unsigned long long k = f64_order_key(v);
+			if (v == v && k > local) local = k;
+		}
+	}
+	if (!PLAIN) {
+		for (int off = 32; off > 0; off >>= 1) {
+			unsigned long long o = __shfl_xor(local, off);
+			if (o > local) local = o;
+		}
+		if ((threadIdx.x & 63) == 0 && local) atomicMax(max_key, local);
+	}
+}
+
+// ----------------------------------------------------------------- render ----
+struct DevRay {
+	double px, py, pz;
+	double dx, dy, dz;
+};
+
+template <int PROJ>
+__device__ __forceinline__ DevRay make_ray(const DevFrame &f, int px, int py) {
+	DevRay r;
+	if (PROJ == 2) {
+		// Spherical.cpp:23-25; sin/cos come from the host tables
+		const double sva = f.row_sin_va[py], cva = f.row_cos_va[py];
+		const double cha = f.col_cos_ha[px], sha = f.col_sin_ha[px];
+		r.px = f.cam[0]; r.py = f.cam[1]; r.pz = f.cam[2];
+		r.dx = sva * cha;
+		r.dy = sva * sha;
+		r.dz = cva;
+	} else {
+		// hmap.cpp:985-988
+		const double w = (double)px / (double)(f.screen_w - 1);
+		const double h = (double)py / (double)(f.screen_h - 1);
+		// upper_left + w*plane_right + h*plane_down  (Perspective.cpp:27, Orthographic.cpp:20)
+		const double ox = (f.upper_left[0] + w * f.plane_right[0]) + h * f.plane_down[0];
+		const double oy = (f.upper_left[1] + w * f.plane_right[1]) + h * f.plane_down[1];
+		const double oz = (f.upper_left[2] + w * f.plane_right[2]) + h * f.plane_down[2];
+		if (PROJ == 1) {
+			const double vx = ox - f.cam[0], vy = oy - f.cam[1], vz = oz - f.cam[2];
+			// glm::normalize: v * (1 / sqrt(dot(v,v))), dot = (x*x + y*y) + z*z
+			const double tx = vx * vx, ty = vy * vy, tz = vz * vz;
+			const double inv = 1.0 / __builtin_sqrt((tx + ty) + tz);
+			r.px = f.cam[0]; r.py = f.cam[1]; r.pz = f.cam[2];
+			r.dx = vx * inv;
+			r.dy = vy * inv;
+			r.dz = vz * inv;
+		} else {
+			r.px = ox; r.py = oy; r.pz = oz;
+			r.dx = f.look[0]; r.dy = f.look[1]; r.dz = f.look[2];
+		}
+	}
+	return r;
+}
+
+// AABB.cpp:49-77, axis order x,y,z, same comparisons (NaN => every test false).
+__device__ __forceinline__ double slab_distance(const DevRay &r, const DevFrame &f) {
+	const double inf = __builtin_huge_val();
+	double lo = -inf, hi = inf;
+	const double ro[3] = {r.px, r.py, r.pz};
+	const double rd[3] = {r.dx, r.dy, r.dz};
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		double dim_lo = (f.c0[i] - ro[i]) / rd[i];
+		double dim_hi = (f.c1[i] - ro[i]) / rd[i];
+		if (dim_lo > dim_hi) {
+			const double t = dim_lo;
+			dim_lo = dim_hi;
+			dim_hi = t;
+		}
+		if (dim_hi < lo || dim_lo > hi) return inf;
+		if (dim_lo > lo) lo = dim_lo;
+		if (dim_hi < hi) hi = dim_hi;
+	}
+	return (lo > hi) ? inf : lo;
+}
+
+__device__ __forceinline__ uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b) {
+	return r | (g << 8) | (b << 16) | 0xff000000u; // bytes R,G,B,A=255 (hmap.cpp:150-153)
+}
+
+// Clamp<double>(v,0,255) then floor then (Uint8), hmap.cpp:1049-1051
+__device__ __forceinline__ uint32_t sky_channel(double v) {
+	if (v < 0.0) v = 0.0;
+	else if (v > 255.0) v = 255.0;
+	return (uint32_t)(int)__builtin_floor(v);
+}
+
+struct StatsOut {
+	unsigned long long *counters; // [0] steps [1] hits [2] capped
+	uint32_t *steps_per_pixel;    // screen_w*screen_h or null
+	double *entry_d;              // screen_w*screen_h or null
+};
+
+template <int PROJ, bool STATS>
+__global__ __launch_bounds__(256) void k_render(const DevFrame f, const RowMap rows,
+                                                const double *__restrict__ thr,
+                                                const uint32_t *__restrict__ cmap,
+                                                uint32_t *__restrict__ out, int64_t out_stride_px,
+                                                int tiles_x, StatsOut st) {
+	// 16x16 pixel tile per workgroup, one 8x8 sub-tile per wave: neighbouring rays
+	// walk neighbouring ground tracks, so a wave's height loads share cache lines
+	// and its lanes leave the loop at similar times.
+	const int tile = blockIdx.x;
+	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+	const int lrow = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+
+	int py; // global framebuffer row of this lane
+	if (rows.band_rows > 0) {
+		const int band = lrow / rows.band_rows, within = lrow - band * rows.band_rows;
+		py = (rows.band_index + band * rows.band_count) * rows.band_rows + within;
+	} else {
+		py = rows.row_begin + lrow;
+	}
+	const bool live = px < f.screen_w && lrow < rows.local_rows && py < f.screen_h;
+
+	unsigned long long my_steps = 0;
+	uint32_t my_hit = 0, my_cap = 0;
+
+	if (live) {
+		const DevRay ray = make_ray<PROJ>(f, px, py);
+		const double d = slab_distance(ray, f);
+		if (STATS && st.entry_d) st.entry_d[(int64_t)py * f.screen_w + px] = d;
+
+		uint32_t rgba = 0;
+		bool real_hit = false;
+
+		// intersection(): AABB.cpp:33-44
+		if (!(d == __builtin_huge_val()) && !(d < 0.0)) {
+			double x = ray.px + d * ray.dx;
+			double y = ray.py + d * ray.dy;
+			double z = ray.pz + d * ray.dz;
+			// hmap.cpp:998  int_point += (grid_width*0.01) * dir
+			x = x + f.nudge * ray.dx;
+			y = y + f.nudge * ray.dy;
+			z = z + f.nudge * ray.dz;
+			// hmap.cpp:1037  step_dist * dir is the same three products every iteration
+			const double sx = f.step_dist * ray.dx;
+			const double sy = f.step_dist * ray.dy;
+			const double sz = f.step_dist * ray.dz;
+			const double wlim = (double)f.map_w, hlim = (double)f.map_h;
+			const double c0x = f.c0[0], c0y = f.c0[1];
+			const bool pow2 = f.grid_pow2 != 0;
+			int64_t budget = f.step_cap;
+
+			for (;;) {
+				// hmap.cpp:1001-1004
+				double qx, qy;
+				if (pow2) {
+					qx = (x - c0x) * f.inv_grid_width;
+					qy = -(y - c0y) * f.inv_grid_width;
+				} else {
+					qx = (x - c0x) / f.grid_width;
+					qy = -(y - c0y) / f.grid_width;
+				}
+				// hmap.cpp:1006-1011: (int)q >= 0  <=>  q > -1 ;  (int)q < W  <=>  q < W
+				if (!(qx > -1.0 && qx < wlim && qy > -1.0 && qy < hlim)) break;
+				if (budget-- <= 0) { my_cap = 1; break; }
+				const int gridx = (int)qx, gridy = (int)qy;
+				const int64_t cell = (int64_t)gridy * f.map_w + gridx;
+				const double t = thr[cell]; // hmap.cpp:1013-1014 (+ c0.z folded in)
+				if (STATS) my_steps += 1;
+				if (z < t) { // hmap.cpp:1016
+					const uint32_t c = cmap[cell];
+					rgba = ((c >> 24) == 0) ? pack_rgba(f.bg[0], f.bg[1], f.bg[2]) : (c | 0xff000000u);
+					real_hit = true;
+					break;
+				}
+				x = x + sx;
+				y = y + sy;
+				z = z + sz;
+			}
+		}
+
+		if (!real_hit) {
+			// hmap.cpp:1041-1057
+			if (ray.dz > 0.0) {
+				const double zz = ray.dz * ray.dz; // std::pow(z,2) == z*z under -std=c++98
+				const double r_ = 220.0 * zz + (double)f.bg[0];
+				const double g_ = 240.0 * zz + (double)f.bg[1];
+				const double b_ = 255.0 * ray.dz + (double)f.bg[2];
+				rgba = pack_rgba(sky_channel(r_), sky_channel(g_), sky_channel(b_));
+			} else {
+				rgba = pack_rgba(f.bg[0], f.bg[1], f.bg[2]);
+			}
+		} else {
+			my_hit = 1;
+		}
+		out[(int64_t)lrow * out_stride_px + px] = rgba;
+		if (STATS && st.steps_per_pixel)
+			st.steps_per_pixel[(int64_t)py * f.screen_w + px] =
+			    my_steps > 0xffffffffull ? 0xffffffffu : (uint32_t)my_steps;
+	}
+
+	if (STATS) {
+		unsigned long long s = my_steps, h = my_hit, c = my_cap;
+		for (int off = 32; off > 0; off >>= 1) {
+			s += __shfl_xor(s, off);
+			h += __shfl_xor(h, off);
+			c += __shfl_xor(c, off);
+		}
+		if (lane == 0) {
+			if (s) atomicAdd(&st.counters[0], s);
+			if (h) atomicAdd(&st.counters[1], h);
+			if (c) atomicAdd(&st.counters[2], c);
+		}
+	} else if (my_cap) {
+		atomicAdd(&st.counters[2], 1ull);
+	}
+}
+
+// Per-ray parity hook: GetRay + distance() of one pixel -> out[0..2] pos, [3..5] dir, [6] d.
+template <int PROJ>
+__global__ void k_probe(const DevFrame f, int px, int py, double *__restrict__ out) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	const DevRay r = make_ray<PROJ>(f, px, py);
+	out[0] = r.px; out[1] = r.py; out[2] = r.pz;
+	out[3] = r.dx; out[4] = r.dy; out[5] = r.dz;
+	out[6] = slab_distance(r, f);
+}
+
+// ------------------------------------------------------------- launchers ----
+hipError_t launch_probe(const DevFrame &f, int px, int py, double *d_out7, hipStream_t stream) {
+	switch (f.projection) {
+	case 1: hipLaunchKernelGGL(k_probe<1>, dim3(1), dim3(64), 0, stream, f, px, py, d_out7); break;
+	case 2: hipLaunchKernelGGL(k_probe<2>, dim3(1), dim3(64), 0, stream, f, px, py, d_out7); break;
+	default: hipLaunchKernelGGL(k_probe<3>, dim3(1), dim3(64), 0, stream, f, px, py, d_out7); break;
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_prepare_heights(const uint8_t *d_rgb, double *d_out, int64_t n, double lum_r,
+                                  double lum_g, double lum_b, double min_h, double max_h, bool plain,
+                                  unsigned long long *d_max_key, hipStream_t stream) {
+	int64_t blocks = (n + 255) / 256;
+	if (blocks > 256 * 8) blocks = 256 * 8; // grid-stride the rest
+	if (blocks < 1) blocks = 1;
+	if (plain)
+		hipLaunchKernelGGL(k_prepare_heights<true>, dim3((unsigned)blocks), dim3(256), 0, stream, d_rgb,
+		                   d_out, n, lum_r, lum_g, lum_b, min_h, max_h, d_max_key);
+	else
+		hipLaunchKernelGGL(k_prepare_heights<false>, dim3((unsigned)blocks), dim3(256), 0, stream, d_rgb,
+		                   d_out, n, lum_r, lum_g, lum_b, min_h, max_h, d_max_key);
+	return hipGetLastError();
+}
+
+double max_key_to_double(unsigned long long key) {
+	unsigned long long b = (key & 0x8000000000000000ull) ? (key & 0x7fffffffffffffffull) : ~key;
+	double v;
+	__builtin_memcpy(&v, &b, sizeof v);
+	return v;
+}
+
+template <bool STATS>
+static hipError_t launch_render_t(const DevFrame &f, const RowMap &rows, const double *d_thr,
+                                  const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
+                                  StatsOut st, hipStream_t stream) {
+	const int tiles_x = (f.screen_w + 15) / 16;
+	const int tiles_y = (rows.local_rows + 15) / 16;
+	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
+	const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y)), block(256);
+	switch (f.projection) {
+	case 1:
+		hipLaunchKernelGGL((k_render<1, STATS>), grid, block, 0, stream, f, rows, d_thr, d_cmap, d_out,
+		                   out_stride_px, tiles_x, st);
+		break;
+	case 2:
+		hipLaunchKernelGGL((k_render<2, STATS>), grid, block, 0, stream, f, rows, d_thr, d_cmap, d_out,
+		                   out_stride_px, tiles_x, st);
+		break;
+	default:
+		hipLaunchKernelGGL((k_render<3, STATS>), grid, block, 0, stream, f, rows, d_thr, d_cmap, d_out,
+		                   out_stride_px, tiles_x, st);
+		break;
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_render(const DevFrame &f, const RowMap &rows, const double *d_thr,
+                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
+                         unsigned long long *d_counters, uint32_t *d_steps, double *d_entry,
+                         bool stats, hipStream_t stream) {
+	StatsOut st{d_counters, d_steps, d_entry};
+	return stats ? launch_render_t<true>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, stream)
+	             : launch_render_t<false>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, stream);
+}
+
+} // namespace hmrm

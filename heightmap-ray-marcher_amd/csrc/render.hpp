@@ -1,0 +1,29 @@
+// render.hpp -- launch interface of render.hip (device code) for api.cpp.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "frame.hpp"
+
+namespace hmrm {
+
+// UpdateHeightmap on the device.  plain=false writes thr[i] = heightmap_buf[i] + min_h and
+// folds max(thr) into *d_max_key (order-preserving key, zero-initialised by the caller);
+// plain=true writes heightmap_buf[i] itself (test hook).
+hipError_t launch_prepare_heights(const uint8_t *d_rgb, double *d_out, int64_t n, double lum_r,
+                                  double lum_g, double lum_b, double min_h, double max_h, bool plain,
+                                  unsigned long long *d_max_key, hipStream_t stream);
+double max_key_to_double(unsigned long long key);
+
+// One pass of the pixel loop over the rows described by `rows`, into d_out
+// (uint32 RGBA per pixel, out_stride_px pixels per local row).
+// d_counters: 3 x uint64 {steps, hits, capped}; steps/hits only filled when stats.
+hipError_t launch_render(const DevFrame &f, const RowMap &rows, const double *d_thr,
+                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
+                         unsigned long long *d_counters, uint32_t *d_steps, double *d_entry,
+                         bool stats, hipStream_t stream);
+
+// GetRay + distance() of pixel (px,py): d_out7 = pos[3], dir[3], d.
+hipError_t launch_probe(const DevFrame &f, int px, int py, double *d_out7, hipStream_t stream);
+
+} // namespace hmrm

@@ -1,0 +1,362 @@
+"""ctypes binding of libhmrm.so (C ABI: include/hmrm.h).
+
+This module is plumbing only: it loads the in-tree shared library built from
+csrc/ and exposes thin wrappers.  There is NO Python or CPU fallback for the hot
+path -- if the library is missing, import fails loudly; if no GPU is usable, the
+render calls raise HmrmError(HMRM_E_DEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmrm.so")
+
+HMRM_OK = 0
+HMRM_E_ARG, HMRM_E_IO, HMRM_E_IMAGE, HMRM_E_CONFIG, HMRM_E_DEVICE, HMRM_E_NOTERM = -1, -2, -3, -4, -5, -6
+PERSPECTIVE, SPHERICAL, ORTHOGRAPHIC = 1, 2, 3
+_PROJ_NAMES = {"perspective": 1, "spherical": 2, "orthographic": 3}
+
+
+class HmrmError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"hmrm error {code}: {msg}")
+        self.code = code
+        self.message = msg
+
+
+class SceneParams(C.Structure):
+    """hmrm_scene_params -- defaults are main/hmap.cpp:38-47,65."""
+    _fields_ = [("min_height", C.c_double), ("max_height", C.c_double),
+                ("lum_r", C.c_double), ("lum_g", C.c_double), ("lum_b", C.c_double),
+                ("grid_width", C.c_double)]
+
+    @classmethod
+    def make(cls, min_height=0.0, max_height=10.0, lum=(0.299, 0.587, 0.114), grid_width=0.05):
+        return cls(min_height, max_height, lum[0], lum[1], lum[2], grid_width)
+
+
+class Camera(C.Structure):
+    """hmrm_camera -- angles in radians; defaults are main/hmap.cpp:31-35,68,75-85,98,107,110-112."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("projection", C.c_int32),
+                ("bg_r", C.c_uint8), ("bg_g", C.c_uint8), ("bg_b", C.c_uint8), ("pad_", C.c_uint8),
+                ("hfov", C.c_double), ("hang", C.c_double), ("vang", C.c_double),
+                ("pos", C.c_double * 3), ("ortho_width", C.c_double), ("step_dist", C.c_double)]
+
+    @classmethod
+    def make(cls, width=800, height=600, projection=PERSPECTIVE, hfov=np.pi / 2.0, hang=-np.pi / 4.0,
+             vang=np.pi / 2.0, pos=(-5.0, 5.0, 0.0), ortho_width=0.1, step_dist=0.25, bg=(0, 0, 0)):
+        if isinstance(projection, str):
+            projection = _PROJ_NAMES[projection]
+        c = cls()
+        c.width, c.height, c.projection = int(width), int(height), int(projection)
+        c.bg_r, c.bg_g, c.bg_b = (int(v) & 255 for v in bg)
+        c.hfov, c.hang, c.vang = float(hfov), float(hang), float(vang)
+        c.pos[0], c.pos[1], c.pos[2] = (float(v) for v in pos)
+        c.ortho_width, c.step_dist = float(ortho_width), float(step_dist)
+        return c
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("hits", C.c_uint64), ("capped", C.c_uint64)]
+
+
+def degrees_to_rads(deg: float) -> float:
+    """DegreesToRads, main/hmap.cpp:131-133 (same two operations, same order)."""
+    return (float(deg) / 180.0) * float(np.pi)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C heightmap-ray-marcher_amd/csrc` (there is no fallback path)")
+    lib = C.CDLL(LIB_PATH)
+    u8p, dp, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.POINTER(C.c_uint32)
+    vp, i32 = C.c_void_p, C.c_int32
+    sig = {
+        "hmrm_abi_version": (C.c_int, []),
+        "hmrm_last_error": (C.c_char_p, []),
+        "hmrm_device_count": (C.c_int, []),
+        "hmrm_set_device": (C.c_int, [C.c_int]),
+        "hmrm_scene_create": (C.c_int, [vp, vp, i32, i32, C.POINTER(SceneParams), C.POINTER(vp)]),
+        "hmrm_scene_update": (C.c_int, [vp, C.POINTER(SceneParams)]),
+        "hmrm_scene_destroy": (None, [vp]),
+        "hmrm_scene_read_heights": (C.c_int, [vp, vp]),
+        "hmrm_render": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t]),
+        "hmrm_render_rows_device": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, i32, i32, i32, i32, i32, vp]),
+        "hmrm_band_local_rows": (i32, [i32, i32, i32, i32]),
+        "hmrm_render_stats": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(Stats), vp, vp]),
+        "hmrm_debug_ray": (C.c_int, [vp, C.POINTER(Camera), i32, i32, dp, dp, dp]),
+        "hmrm_last_kernel_ms": (C.c_double, []),
+        "hmrm_bench_kernel_ms": (C.c_double, [vp, C.POINTER(Camera), i32]),
+        "hmrm_config_create": (vp, []),
+        "hmrm_config_destroy": (None, [vp]),
+        "hmrm_config_consume_file": (C.c_int, [vp, C.c_char_p]),
+        "hmrm_config_consume_string": (C.c_int, [vp, C.c_char_p]),
+        "hmrm_config_log": (C.c_char_p, [vp]),
+        "hmrm_config_warnings": (C.c_char_p, [vp]),
+        "hmrm_config_get_camera": (None, [vp, C.POINTER(Camera)]),
+        "hmrm_config_get_scene_params": (None, [vp, C.POINTER(SceneParams)]),
+        "hmrm_config_cycle": (i32, [vp]),
+        "hmrm_config_recording_frame_count": (i32, [vp]),
+        "hmrm_config_heightmap_path": (C.c_char_p, [vp]),
+        "hmrm_config_colormap_path": (C.c_char_p, [vp]),
+        "hmrm_config_output_path": (C.c_char_p, [vp]),
+        "hmrm_config_height_rgb": (u8p, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "hmrm_config_color_rgba": (u8p, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "hmrm_config_take_heightmap_dirty": (C.c_int, [vp]),
+        "hmrm_config_create_scene": (C.c_int, [vp, C.POINTER(vp)]),
+        "hmrm_image_load": (C.c_int, [C.c_char_p, i32, C.POINTER(u8p), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "hmrm_image_load_memory": (C.c_int, [vp, C.c_size_t, i32, C.POINTER(u8p), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "hmrm_image_free": (None, [vp]),
+        "hmrm_write_png": (C.c_int, [C.c_char_p, i32, i32, i32, vp, C.c_size_t]),
+        "hmrm_write_png_memory": (C.c_int, [i32, i32, i32, vp, C.c_size_t, C.POINTER(u8p), C.POINTER(C.c_size_t)]),
+        "hmrm_write_ppm": (C.c_int, [C.c_char_p, i32, i32, i32, vp, C.c_size_t]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = the ABI lost a symbol: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    del u32p
+    return lib, tuple(sig.keys())
+
+
+lib, EXPORTED_SYMBOLS = _load()
+
+
+def last_error() -> str:
+    return (lib.hmrm_last_error() or b"").decode("utf-8", "replace")
+
+
+def _check(rc: int, allow=()):
+    if rc != HMRM_OK and rc not in allow:
+        raise HmrmError(rc, last_error())
+    return rc
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    n = lib.hmrm_device_count()
+    if n < 0:
+        raise HmrmError(n, last_error())
+    return n
+
+
+def set_device(i: int):
+    _check(lib.hmrm_set_device(int(i)))
+
+
+class Scene:
+    """Device-resident height + colour maps (replaces the globals filled at hmap.cpp:314-353)."""
+
+    def __init__(self, height_rgb: np.ndarray, color_rgba: np.ndarray, params: SceneParams):
+        h_rgb = np.ascontiguousarray(height_rgb, dtype=np.uint8)
+        c_rgba = np.ascontiguousarray(color_rgba, dtype=np.uint8)
+        if h_rgb.ndim != 3 or h_rgb.shape[2] != 3:
+            raise ValueError("height_rgb must be HxWx3 uint8")
+        if c_rgba.shape != (h_rgb.shape[0], h_rgb.shape[1], 4):
+            # hmap.cpp:503-515
+            raise ValueError(f"heightmap dimensions ({h_rgb.shape[1]}x{h_rgb.shape[0]}) must match colormap "
+                             f"dimensions ({c_rgba.shape[1]}x{c_rgba.shape[0]})")
+        self.map_h, self.map_w = int(h_rgb.shape[0]), int(h_rgb.shape[1])
+        self.params = params
+        self._h = C.c_void_p()
+        _check(lib.hmrm_scene_create(_ptr(h_rgb), _ptr(c_rgba), self.map_w, self.map_h,
+                                     C.byref(params), C.byref(self._h)))
+
+    @classmethod
+    def _adopt(cls, handle, map_w, map_h, params):
+        s = cls.__new__(cls)
+        s._h, s.map_w, s.map_h, s.params = handle, map_w, map_h, params
+        return s
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.hmrm_scene_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def update(self, params: SceneParams):
+        _check(lib.hmrm_scene_update(self._h, C.byref(params)))
+        self.params = params
+
+    def read_heights(self) -> np.ndarray:
+        out = np.empty((self.map_h, self.map_w), dtype=np.float64)
+        _check(lib.hmrm_scene_read_heights(self._h, _ptr(out)))
+        return out
+
+    def render(self, cam: Camera) -> np.ndarray:
+        """One full frame (hmap.cpp:978-1058 at `cycle 1`) -> HxWx4 uint8."""
+        fb = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
+        _check(lib.hmrm_render(self._h, C.byref(cam), _ptr(fb), cam.width * 4))
+        return fb
+
+    def render_stats(self, cam: Camera, per_pixel=False, allow_capped=False):
+        fb = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
+        st = Stats()
+        steps = np.empty((cam.height, cam.width), dtype=np.uint32) if per_pixel else None
+        entry = np.empty((cam.height, cam.width), dtype=np.float64) if per_pixel else None
+        _check(lib.hmrm_render_stats(self._h, C.byref(cam), _ptr(fb), cam.width * 4, C.byref(st),
+                                     _ptr(steps) if per_pixel else None, _ptr(entry) if per_pixel else None),
+               allow=(HMRM_E_NOTERM,) if allow_capped else ())
+        return fb, st, steps, entry
+
+    def render_rows_device(self, cam: Camera, d_ptr: int, stride_bytes: int, row_begin=0, row_end=0,
+                           band_rows=0, band_index=0, band_count=1, stream: int = 0):
+        _check(lib.hmrm_render_rows_device(self._h, C.byref(cam), C.c_void_p(d_ptr), stride_bytes,
+                                           row_begin, row_end, band_rows, band_index, band_count,
+                                           C.c_void_p(stream)))
+
+    def debug_ray(self, cam: Camera, px: int, py: int):
+        pos, dirv, d = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
+        _check(lib.hmrm_debug_ray(self._h, C.byref(cam), px, py, pos, dirv, C.byref(d)))
+        return np.array(pos[:]), np.array(dirv[:]), d.value
+
+    def bench_kernel_ms(self, cam: Camera, iters: int) -> float:
+        ms = lib.hmrm_bench_kernel_ms(self._h, C.byref(cam), int(iters))
+        if ms < 0:
+            raise HmrmError(HMRM_E_DEVICE, last_error())
+        return ms
+
+
+def band_local_rows(height, band_rows, band_index, band_count) -> int:
+    return int(lib.hmrm_band_local_rows(height, band_rows, band_index, band_count))
+
+
+class Config:
+    """The reference's config grammar (ConsumeConfigStream, hmap.cpp:309-520)."""
+
+    def __init__(self):
+        self._h = C.c_void_p(lib.hmrm_config_create())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.hmrm_config_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def consume_string(self, text: str):
+        _check(lib.hmrm_config_consume_string(self._h, text.encode()))
+        return self
+
+    def consume_file(self, path: str):
+        _check(lib.hmrm_config_consume_file(self._h, os.fsencode(path)))
+        return self
+
+    @property
+    def log(self) -> str:
+        return lib.hmrm_config_log(self._h).decode()
+
+    @property
+    def warnings(self) -> str:
+        return lib.hmrm_config_warnings(self._h).decode()
+
+    def camera(self) -> Camera:
+        c = Camera()
+        lib.hmrm_config_get_camera(self._h, C.byref(c))
+        return c
+
+    def scene_params(self) -> SceneParams:
+        p = SceneParams()
+        lib.hmrm_config_get_scene_params(self._h, C.byref(p))
+        return p
+
+    @property
+    def cycle(self) -> int:
+        return lib.hmrm_config_cycle(self._h)
+
+    @property
+    def recording_frame_count(self) -> int:
+        return lib.hmrm_config_recording_frame_count(self._h)
+
+    @property
+    def heightmap_path(self) -> str:
+        return lib.hmrm_config_heightmap_path(self._h).decode()
+
+    @property
+    def colormap_path(self) -> str:
+        return lib.hmrm_config_colormap_path(self._h).decode()
+
+    @property
+    def output_path(self) -> str:
+        return lib.hmrm_config_output_path(self._h).decode()
+
+    def take_heightmap_dirty(self) -> bool:
+        return bool(lib.hmrm_config_take_heightmap_dirty(self._h))
+
+    def _map(self, fn, comp):
+        w, h = C.c_int32(), C.c_int32()
+        p = fn(self._h, C.byref(w), C.byref(h))
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, comp)).copy()
+
+    def height_rgb(self):
+        return self._map(lib.hmrm_config_height_rgb, 3)
+
+    def color_rgba(self):
+        return self._map(lib.hmrm_config_color_rgba, 4)
+
+    def create_scene(self) -> Scene:
+        h = C.c_void_p()
+        _check(lib.hmrm_config_create_scene(self._h, C.byref(h)))
+        rgb = self.height_rgb()
+        return Scene._adopt(h, rgb.shape[1], rgb.shape[0], self.scene_params())
+
+
+def image_load(path: str, req_comp: int):
+    """stbi_load(path,&w,&h,&n,req_comp) replacement -> (HxWxC uint8, channels_in_file)."""
+    out = C.POINTER(C.c_uint8)()
+    w, h, n = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib.hmrm_image_load(os.fsencode(path), req_comp, C.byref(out), C.byref(w), C.byref(h), C.byref(n)))
+    comp = req_comp if req_comp else n.value
+    arr = np.ctypeslib.as_array(out, shape=(h.value, w.value, comp)).copy()
+    lib.hmrm_image_free(out)
+    return arr, n.value
+
+
+def image_load_memory(data: bytes, req_comp: int):
+    out = C.POINTER(C.c_uint8)()
+    w, h, n = C.c_int32(), C.c_int32(), C.c_int32()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    _check(lib.hmrm_image_load_memory(buf, len(data), req_comp, C.byref(out), C.byref(w), C.byref(h), C.byref(n)))
+    comp = req_comp if req_comp else n.value
+    arr = np.ctypeslib.as_array(out, shape=(h.value, w.value, comp)).copy()
+    lib.hmrm_image_free(out)
+    return arr, n.value
+
+
+def png_encode(img: np.ndarray) -> bytes:
+    """stbi_write_png_to_mem replacement (same bytes as stb_image_write v1.16)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    h, w, comp = img.shape
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    _check(lib.hmrm_write_png_memory(w, h, comp, _ptr(img), w * comp, C.byref(out), C.byref(n)))
+    data = bytes(np.ctypeslib.as_array(out, shape=(n.value,)))
+    lib.hmrm_image_free(out)
+    return data
+
+
+def write_png(path: str, img: np.ndarray):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, comp = img.shape
+    _check(lib.hmrm_write_png(os.fsencode(path), w, h, comp, _ptr(img), w * comp))
+
+
+def write_ppm(path: str, img: np.ndarray):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, comp = img.shape
+    _check(lib.hmrm_write_ppm(os.fsencode(path), w, h, comp, _ptr(img), w * comp))

@@ -1,0 +1,209 @@
+/*
+ * hmrm.h -- C ABI of libhmrm.so, the MI355X-native (gfx950) heightmap ray
+ * marcher.  This is the drop-in boundary for the reference's hot path.
+ *
+ * The reference (Costava/heightmap-ray-marcher) has no FFI/plugin boundary: the
+ * path is inline in main() and talks through file-scope globals
+ * (main/hmap.cpp:28-112).  The contract a replacement has to honour is
+ *     config text in  ->  RGBA8 framebuffer / PNG out.
+ * Each entry point below names the reference interface it replaces.  All
+ * pointers are plain host pointers unless the name says "device"; no torch, HIP
+ * or C++ types appear in any signature.  All functions returning int return
+ * HMRM_OK (0) or a negative HMRM_E_* code; hmrm_last_error() then holds the
+ * message the reference would have printed to stderr before exit(1).
+ *
+ * There is NO CPU fallback: entry points that render fail with HMRM_E_DEVICE
+ * when no gfx950 device / HIP runtime is usable.
+ */
+#ifndef HMRM_H
+#define HMRM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMRM_ABI_VERSION 1
+
+enum {
+	HMRM_OK          =  0,
+	HMRM_E_ARG       = -1,  /* bad argument / inconsistent sizes                       */
+	HMRM_E_IO        = -2,  /* file cannot be opened / written (hmap.cpp:537-540,162)   */
+	HMRM_E_IMAGE     = -3,  /* image cannot be decoded (hmap.cpp:324-329,345-350)       */
+	HMRM_E_CONFIG    = -4,  /* config validation failed (hmap.cpp:493-515)              */
+	HMRM_E_DEVICE    = -5,  /* HIP error / no device                                    */
+	HMRM_E_NOTERM    = -6   /* a ray hit the step cap: the reference loop would not end */
+};
+
+/* main/hmap.cpp:104-106 IMAGEPLANE_* */
+enum {
+	HMRM_PERSPECTIVE  = 1,
+	HMRM_SPHERICAL    = 2,
+	HMRM_ORTHOGRAPHIC = 3
+};
+
+/* The globals UpdateHeightmap() and the box corners read:
+ * main/hmap.cpp:38-47 (min/max_height, lum_*), :65 (grid_width). */
+typedef struct hmrm_scene_params {
+	double min_height;   /* default 0.0   */
+	double max_height;   /* default 10.0  */
+	double lum_r;        /* default 0.299 */
+	double lum_g;        /* default 0.587 */
+	double lum_b;        /* default 0.114 */
+	double grid_width;   /* default 0.05  */
+} hmrm_scene_params;
+
+/* The globals the per-frame set-up and the pixel loop read:
+ * main/hmap.cpp:31-35 (resolution, hfov), :68 (step_dist), :75-85 (pos, hang,
+ * vang), :98 (ortho_width), :107 (image_plane), :110-112 (bg).  Angles are in
+ * RADIANS here (the config file holds degrees, hmap.cpp:131-133,367-384). */
+typedef struct hmrm_camera {
+	int32_t  width;        /* screen_width  */
+	int32_t  height;       /* screen_height */
+	int32_t  projection;   /* HMRM_PERSPECTIVE | HMRM_SPHERICAL | HMRM_ORTHOGRAPHIC */
+	uint8_t  bg_r, bg_g, bg_b, pad_;
+	double   hfov;
+	double   hang;
+	double   vang;
+	double   pos[3];
+	double   ortho_width;
+	double   step_dist;
+} hmrm_camera;
+
+/* Per-render statistics (build-side addition; BASELINE.md metric definitions). */
+typedef struct hmrm_stats {
+	uint64_t rays;        /* pixels rendered                                          */
+	uint64_t steps;       /* height loads the reference loop executes (hmap.cpp:1013) */
+	uint64_t hits;        /* rays that end on terrain (hmap.cpp:1016)                 */
+	uint64_t capped;      /* rays stopped by the step cap (reference: endless loop)   */
+} hmrm_stats;
+
+typedef struct hmrm_scene hmrm_scene;    /* device-resident height + colour maps */
+typedef struct hmrm_config hmrm_config;  /* parsed config state                  */
+
+/* ------------------------------------------------------------------ general */
+int         hmrm_abi_version(void);
+const char *hmrm_last_error(void);              /* thread-local, never NULL */
+int         hmrm_device_count(void);            /* <0 on HIP error          */
+int         hmrm_set_device(int device);
+
+/* -------------------------------------------------------------------- scene */
+/* Replaces the stbi_load results + UpdateHeightmap (hmap.cpp:314-353,171-191):
+ * height_rgb is W*H*3 RGB8 (stbi_load req_comp 3), color_rgba W*H*4 RGBA8
+ * (req_comp 4), both row-major top-left origin.  Uploads both once; heights are
+ * converted on the device with the reference's exact operation order. */
+int  hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba,
+                       int32_t map_w, int32_t map_h,
+                       const hmrm_scene_params *params, hmrm_scene **out);
+/* Re-run UpdateHeightmap after min/max_height, lum_* (or grid_width) changed
+ * (hmap.cpp:401-440,517-519). */
+int  hmrm_scene_update(hmrm_scene *scene, const hmrm_scene_params *params);
+void hmrm_scene_destroy(hmrm_scene *scene);
+/* Copies the device height buffer (heightmap_buf, hmap.cpp:53,187) to `out`
+ * (map_w*map_h doubles) -- test hook for UpdateHeightmap parity. */
+int  hmrm_scene_read_heights(const hmrm_scene *scene, double *out);
+
+/* ------------------------------------------------------------------- render */
+/* Replaces one pass of the pixel loop main/hmap.cpp:978-1058 at `cycle 1` plus
+ * the per-frame set-up :661-672,:952-974.  Writes every pixel of the
+ * width x height RGBA8 frame (bytes R,G,B,A=255, top-left origin,
+ * hmap.cpp:139-154) to host memory; stride_bytes >= width*4. */
+int hmrm_render(const hmrm_scene *scene, const hmrm_camera *cam,
+                uint8_t *rgba, size_t stride_bytes);
+
+/* Same pass restricted to rows [row_begin,row_end) of the frame, written to a
+ * DEVICE buffer that holds only those rows (row row_begin at d_rgba), enqueued
+ * on `hip_stream` (a hipStream_t, NULL = default stream) without a host sync.
+ * This is the multi-GPU row-strip entry point. `band_rows`>0 selects cyclic
+ * banding: the strip holds bands band_index, band_index+band_count, ... of
+ * band_rows rows each, packed back to back (row_begin/row_end then ignored). */
+int hmrm_render_rows_device(const hmrm_scene *scene, const hmrm_camera *cam,
+                            void *d_rgba, size_t stride_bytes,
+                            int32_t row_begin, int32_t row_end,
+                            int32_t band_rows, int32_t band_index, int32_t band_count,
+                            void *hip_stream);
+
+/* Rows the strip buffer of one rank must hold in cyclic-band mode (full bands). */
+int32_t hmrm_band_local_rows(int32_t height, int32_t band_rows, int32_t band_index, int32_t band_count);
+
+/* As hmrm_render, plus per-render statistics and optional per-pixel outputs
+ * (host pointers, width*height entries each, may be NULL): the step count of
+ * each ray and the slab-entry distance returned by distance() (AABB.cpp:49-77).
+ * Uses the instrumented kernel variant; pixels are identical. */
+int hmrm_render_stats(const hmrm_scene *scene, const hmrm_camera *cam,
+                      uint8_t *rgba, size_t stride_bytes,
+                      hmrm_stats *stats, uint32_t *steps_per_pixel, double *entry_d);
+
+/* Device-side ImagePlane::GetRay (ImagePlane.hpp:10) and distance()
+ * (AABB.hpp:12) for one pixel -- per-ray parity hooks. */
+int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam,
+                   int32_t px, int32_t py, double pos[3], double dir[3], double *entry_d);
+
+/* Time of the most recent render kernel launch on this thread, measured with
+ * HIP events on the launch stream (ms); <0 if none. Only valid after
+ * hmrm_render / hmrm_render_stats, which synchronise. */
+double hmrm_last_kernel_ms(void);
+
+/* Launches the render kernel `iters` times back to back into a device scratch
+ * frame (no D2H) and returns the mean kernel duration in ms measured with HIP
+ * events on the launch stream; <0 on error.  Bench hook. */
+double hmrm_bench_kernel_ms(const hmrm_scene *scene, const hmrm_camera *cam, int32_t iters);
+
+/* ------------------------------------------------------------------- config */
+/* Replaces ConsumeConfigStream (main/hmap.cpp:309-520) and the globals'
+ * defaults (:31-112).  Same whitespace token grammar, same 27 keys, same echo of
+ * every option to `echo_fd`-style sinks: echo text is appended to an internal
+ * log retrievable with hmrm_config_log().  Additive keys (not in the reference,
+ * named by north_star): `projection perspective|spherical|orthographic|1|2|3`,
+ * `output <path.png|.ppm>`.  Unknown key -> "WARNING: Unknown identifier: k". */
+hmrm_config *hmrm_config_create(void);
+void         hmrm_config_destroy(hmrm_config *cfg);
+/* Consume a whole stream; loads heightmap/colormap images when those keys
+ * appear; runs the end-of-stream validation (maps present, equal dimensions). */
+int          hmrm_config_consume_file(hmrm_config *cfg, const char *path);
+int          hmrm_config_consume_string(hmrm_config *cfg, const char *text);
+const char  *hmrm_config_log(const hmrm_config *cfg);      /* stdout echo so far   */
+const char  *hmrm_config_warnings(const hmrm_config *cfg); /* stderr text so far   */
+void         hmrm_config_get_camera(const hmrm_config *cfg, hmrm_camera *out);
+void         hmrm_config_get_scene_params(const hmrm_config *cfg, hmrm_scene_params *out);
+int32_t      hmrm_config_cycle(const hmrm_config *cfg);
+int32_t      hmrm_config_recording_frame_count(const hmrm_config *cfg);
+const char  *hmrm_config_heightmap_path(const hmrm_config *cfg);
+const char  *hmrm_config_colormap_path(const hmrm_config *cfg);
+const char  *hmrm_config_output_path(const hmrm_config *cfg);
+/* Loaded maps (owned by cfg): RGB8 / RGBA8; NULL until the key was consumed. */
+const uint8_t *hmrm_config_height_rgb(const hmrm_config *cfg, int32_t *w, int32_t *h);
+const uint8_t *hmrm_config_color_rgba(const hmrm_config *cfg, int32_t *w, int32_t *h);
+/* 1 if heights need recomputing since the last call (should_update_heightmap). */
+int          hmrm_config_take_heightmap_dirty(hmrm_config *cfg);
+/* Scene from the loaded maps + params (= hmrm_scene_create on the above). */
+int          hmrm_config_create_scene(const hmrm_config *cfg, hmrm_scene **out);
+
+/* ----------------------------------------------------------------- image IO */
+/* Replaces stbi_load(path,&w,&h,&n,req_comp) (hmap.cpp:320-321,341-342) for the
+ * formats implemented natively: PNG (all colour types / bit depths, interlaced
+ * too) and binary PNM (P5/P6).  Channel conversion follows stb_image v2.27
+ * (16-bit -> 8 by >>8; grey -> RGB replicate; missing alpha = 255).  *out is
+ * malloc'ed; free with hmrm_image_free. */
+int  hmrm_image_load(const char *path, int32_t req_comp,
+                     uint8_t **out, int32_t *w, int32_t *h, int32_t *comp_in_file);
+int  hmrm_image_load_memory(const uint8_t *bytes, size_t len, int32_t req_comp,
+                            uint8_t **out, int32_t *w, int32_t *h, int32_t *comp_in_file);
+void hmrm_image_free(void *p);
+/* Replaces SavePNG / stbi_write_png(path,w,h,comp,data,stride)
+ * (hmap.cpp:157-160): same filter choice and the same deflate as
+ * stb_image_write v1.16, so equal pixels give equal files. */
+int  hmrm_write_png(const char *path, int32_t w, int32_t h, int32_t comp,
+                    const uint8_t *data, size_t stride_bytes);
+int  hmrm_write_png_memory(int32_t w, int32_t h, int32_t comp, const uint8_t *data,
+                           size_t stride_bytes, uint8_t **out, size_t *out_len);
+/* Binary PPM (P6), alpha dropped -- build-side addition named by north_star. */
+int  hmrm_write_ppm(const char *path, int32_t w, int32_t h, int32_t comp,
+                    const uint8_t *data, size_t stride_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMRM_H */
