@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline metric on MI355X (BASELINE.json).
+
+A "step" is one pass of the hot path over one frame of synthetic input: the
+render kernel over every pixel of the workload's framebuffer.  Default workload
+= BASELINE.json configs[2], the configuration the metric is quoted on:
+3840x2160 over a 4096^2 heightmap, spherical hfov 180, step_dist 0.25 ("C3";
+`--workload C3h` is the north_star's step_dist 0.5 variant, C2/C5 also exist).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3]
+  torchrun --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N = 1: K frames back to back, maps resident in HBM, output to a device buffer.
+N > 1: ONE frame is tiled into cyclic 16-row bands, one process per GPU, strips
+       gathered on rank 0 over RCCL (the path north_star names); `value` is
+       whole-job ray-steps/s, scaling "strong".  `--mode frames` instead gives
+       each rank whole frames (config C5 style, no collective, "weak").
+
+Rank 0 prints ONE JSON line.  value = ray-steps/s, where a ray-step is one
+execution of the reference's height load (main/hmap.cpp:1013-1014); the count
+comes from the instrumented kernel variant (bit-identical pixels) run once,
+untimed.  roofline.achieved = algorithmic bytes (8 B/step + 4 B/ray + 4 B/hit,
+BASELINE.md) / mean kernel duration measured with HIP events on the launch
+stream.  cpu_baseline = the oracle (C port of the reference loop, OpenMP) timed
+on a bounded row sample of the same frame on this host.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+BAND_ROWS = 16
+
+
+def _traffic_from_profiles(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary, if one exists
+    for this workload (profiles/traffic.json, written from a separate --pmc pass)."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(hmrm, wl, rgb, cmap, params, cam, target_s=15.0):
+    """Oracle on a bounded sample: every `stride`-th framebuffer row, stride chosen from a
+    quick probe so that the timed run is ~target_s seconds of work on all host cores."""
+    from oracle import oracle_py as oracle
+    heights = oracle.update_heightmap(rgb, params)
+    cfg = oracle.make_cfg(cam, params, wl.map_size, wl.map_size)
+    cores = oracle.max_threads()
+    probe_stride = max(1, cam.height // 16)
+    t0 = time.perf_counter()
+    _, probe_steps, _, _, _ = oracle.render(cfg, heights, cmap, row_stride=probe_stride)
+    probe_t = max(time.perf_counter() - t0, 1e-6)
+    rows_probe = len(range(0, cam.height, probe_stride))
+    per_row = probe_t / rows_probe
+    rows_target = int(min(cam.height, max(rows_probe, target_s / per_row)))
+    stride = max(1, cam.height // rows_target)
+    t0 = time.perf_counter()
+    _, steps, _, _, _ = oracle.render(cfg, heights, cmap, row_stride=stride)
+    dt = time.perf_counter() - t0
+    nrows = len(range(0, cam.height, stride))
+    return {"value": steps / dt, "unit": "ray-steps/s", "cores": cores, "kind": "port",
+            "mrays_per_s": nrows * cam.width / dt / 1e6,
+            "sample": f"every {stride}th row of the {cam.width}x{cam.height} frame ({nrows} rows, "
+                      f"{steps} ray-steps, {dt:.1f} s, gcc -O2 -fopenmp -ffp-contract=off)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--mode", choices=["strips", "frames"], default="strips")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    hmrm = importlib.import_module("heightmap-ray-marcher_amd")
+    strips = importlib.import_module("heightmap-ray-marcher_amd.strips")
+    if not torch.cuda.is_available() or hmrm.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    hmrm.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    wl = hmrm.synth.WORKLOADS[args.workload]
+    rgb, cmap = hmrm.synth.synth_maps(wl.map_size)
+    params, cam = wl.scene_params(), wl.camera()
+    scene = hmrm.Scene(rgb, cmap, params)  # maps resident in HBM from here on
+    W, H = cam.width, cam.height
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # step / hit counts of the frame (instrumented kernel, untimed; pixels identical)
+    fb_ref, st, _, _ = scene.render_stats(cam)
+    frame_steps, frame_rays, frame_hits = int(st.steps), int(st.rays), int(st.hits)
+    algo_bytes = 8 * frame_steps + 4 * frame_rays + 4 * frame_hits
+
+    if world == 1 or args.mode == "frames":
+        out = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+
+        def step():
+            scene.render_rows_device(cam, out.data_ptr(), W * 4, 0, H, stream=stream)
+        units_per_step = frame_steps * world  # every rank renders a whole frame
+        rays_per_step = frame_rays * world
+        scaling = "weak"
+        parallelism = "1 GPU" if world == 1 else f"frame-parallel x{world}, no collective"
+    else:
+        plan = strips.BandPlan(height=H, width=W, band_rows=BAND_ROWS, world=world)
+        strip = torch.zeros((plan.strip_rows, W, 4), dtype=torch.uint8, device="cuda")
+        block = torch.zeros((world, plan.strip_rows, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
+        result = {}
+
+        def render_rows(strip_t, band_rows, band_index, band_count):
+            scene.render_rows_device(cam, strip_t.data_ptr(), W * 4, band_rows=band_rows,
+                                     band_index=band_index, band_count=band_count, stream=stream)
+
+        def step():
+            result["frame"] = strips.render_frame_distributed(plan, rank, render_rows, dist, strip, block)
+        units_per_step = frame_steps
+        rays_per_step = frame_rays
+        scaling = "strong"
+        parallelism = f"cyclic {BAND_ROWS}-row bands over {world} GPUs + RCCL gather to rank 0"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was just timed: the frame on rank 0 equals the single-GPU frame
+    if rank == 0:
+        got = (result["frame"] if (world > 1 and args.mode == "strips") else out).cpu().numpy()
+        if not np.array_equal(got, fb_ref):
+            raise SystemExit("bench.py: timed path produced a different frame than hmrm_render_stats")
+
+    # dominant kernel: mean launch duration by HIP events on the launch stream (full frame, 1 GPU's view)
+    kernel_ms = scene.bench_kernel_ms(cam, max(3, min(args.steps, 20))) if rank == 0 else None
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = units_per_step * args.steps / elapsed
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "ray-steps/s at 3840x2160, 4096^2 heightmap" if wl.map_size == 4096 else
+                      f"ray-steps/s at {W}x{H}, {wl.map_size}^2 heightmap",
+            "value": value, "unit": "ray-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "mrays_per_s": rays_per_step * args.steps / elapsed / 1e6,
+            "config": {"workload": f"{wl.name}: {wl.map_size}x{wl.map_size} heightmap, {W}x{H}, "
+                                   f"{('perspective', 'spherical', 'orthographic')[wl.projection - 1]} "
+                                   f"hfov {wl.hfov_deg:g}, step_dist {wl.step_dist:g}, grid_width 1",
+                       "ray_steps_per_frame": frame_steps, "rays_per_frame": frame_rays,
+                       "hits_per_frame": frame_hits, "parallelism": parallelism,
+                       "maps_sha256": hmrm.synth.maps_sha256(rgb, cmap)[:16]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles(wl.name),
+                         "kernel": "k_render", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel_ray_steps_per_s": frame_steps / (kernel_ms * 1e-3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(hmrm, wl, rgb, cmap, params, cam, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()

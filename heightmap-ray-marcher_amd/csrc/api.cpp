@@ -595,6 +595,38 @@ int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam, int32_t px, 
 	return HMRM_OK;
 }
 
+int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params, int32_t map_w,
+                     int32_t map_h, double *out25, double *tables) {
+	int rc = check_camera(cam);
+	if (rc) return rc;
+	if (!params || !out25) return fail(HMRM_E_ARG, "NULL argument");
+	if (cam->projection == HMRM_SPHERICAL && !tables) return fail(HMRM_E_ARG, "tables required for spherical");
+	hmrm::HostCamera hc{};
+	hc.width = cam->width; hc.height = cam->height; hc.projection = cam->projection;
+	hc.bg_r = cam->bg_r; hc.bg_g = cam->bg_g; hc.bg_b = cam->bg_b;
+	hc.hfov = cam->hfov; hc.hang = cam->hang; hc.vang = cam->vang;
+	hc.pos[0] = cam->pos[0]; hc.pos[1] = cam->pos[1]; hc.pos[2] = cam->pos[2];
+	hc.ortho_width = cam->ortho_width; hc.step_dist = cam->step_dist;
+	const size_t W = (size_t)cam->width, H = (size_t)cam->height;
+	hmrm::DevFrame f;
+	hmrm::build_frame(hc, map_w, map_h, params->min_height, params->max_height, params->grid_width, &f,
+	                  tables, tables ? tables + W : nullptr, tables ? tables + 2 * W : nullptr,
+	                  tables ? tables + 2 * W + H : nullptr);
+	double *o = out25;
+	for (int i = 0; i < 3; ++i) *o++ = f.cam[i];
+	for (int i = 0; i < 3; ++i) *o++ = f.upper_left[i];
+	for (int i = 0; i < 3; ++i) *o++ = f.plane_right[i];
+	for (int i = 0; i < 3; ++i) *o++ = f.plane_down[i];
+	for (int i = 0; i < 3; ++i) *o++ = f.look[i];
+	for (int i = 0; i < 3; ++i) *o++ = f.c0[i];
+	for (int i = 0; i < 3; ++i) *o++ = f.c1[i];
+	*o++ = f.nudge;
+	*o++ = f.step_dist;
+	*o++ = (double)f.grid_pow2;
+	*o++ = f.inv_grid_width;
+	return HMRM_OK;
+}
+
 int32_t hmrm_band_local_rows(int32_t height, int32_t band_rows, int32_t band_index, int32_t band_count) {
 	if (height <= 0 || band_rows <= 0 || band_count <= 0 || band_index < 0 || band_index >= band_count) return 0;
 	int64_t local = 0;

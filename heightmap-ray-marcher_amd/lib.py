@@ -92,6 +92,7 @@ def _load():
         "hmrm_band_local_rows": (i32, [i32, i32, i32, i32]),
         "hmrm_render_stats": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(Stats), vp, vp]),
         "hmrm_debug_ray": (C.c_int, [vp, C.POINTER(Camera), i32, i32, dp, dp, dp]),
+        "hmrm_debug_frame": (C.c_int, [C.POINTER(Camera), C.POINTER(SceneParams), i32, i32, vp, vp]),
         "hmrm_last_kernel_ms": (C.c_double, []),
         "hmrm_bench_kernel_ms": (C.c_double, [vp, C.POINTER(Camera), i32]),
         "hmrm_config_create": (vp, []),
@@ -226,6 +227,21 @@ class Scene:
         if ms < 0:
             raise HmrmError(HMRM_E_DEVICE, last_error())
         return ms
+
+
+def debug_frame(cam: Camera, params: SceneParams, map_w: int, map_h: int):
+    """Host-only per-frame record (no GPU): dict of the DevFrame fields + spherical tables."""
+    out = np.empty(25, dtype=np.float64)
+    tables = np.empty(2 * cam.width + 2 * cam.height, dtype=np.float64)
+    _check(lib.hmrm_debug_frame(C.byref(cam), C.byref(params), map_w, map_h, _ptr(out), _ptr(tables)))
+    W, H = cam.width, cam.height
+    rec = {"cam": out[0:3], "upper_left": out[3:6], "plane_right": out[6:9], "plane_down": out[9:12],
+           "look": out[12:15], "c0": out[15:18], "c1": out[18:21], "nudge": out[21], "step_dist": out[22],
+           "grid_pow2": int(out[23]), "inv_grid_width": out[24]}
+    if cam.projection == SPHERICAL:
+        rec.update(col_cos_ha=tables[0:W], col_sin_ha=tables[W:2 * W],
+                   row_sin_va=tables[2 * W:2 * W + H], row_cos_va=tables[2 * W + H:])
+    return rec
 
 
 def band_local_rows(height, band_rows, band_index, band_count) -> int:

@@ -1,0 +1,85 @@
+"""Multi-GPU row-strip tiling of ONE frame (BASELINE config C4).
+
+Pixels are independent (main/hmap.cpp:978), so the framebuffer shards with no
+exchange during the march.  Each rank holds the whole heightmap and renders a
+cyclic set of row bands (band b goes to rank b % world): sky rows cost ~0 steps
+and terrain rows thousands, so contiguous H/world strips would be badly
+unbalanced.  The only collective is the final gather of the RGBA8 strips to rank
+0 (torch.distributed: RCCL over xGMI with backend "nccl", gloo in CPU tests).
+
+The renderer is passed in as a callable so that the same plan/gather/reassemble
+code runs with the HIP path on GPUs and with any row renderer in CPU tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class BandPlan:
+    height: int        # framebuffer rows
+    width: int
+    band_rows: int
+    world: int
+
+    @property
+    def total_bands(self) -> int:
+        return (self.height + self.band_rows - 1) // self.band_rows
+
+    @property
+    def bands_per_rank(self) -> int:
+        """Every rank's strip is padded to this many bands so that the gather is regular."""
+        return (self.total_bands + self.world - 1) // self.world
+
+    @property
+    def strip_rows(self) -> int:
+        return self.bands_per_rank * self.band_rows
+
+    def bands_of(self, rank: int):
+        return list(range(rank, self.total_bands, self.world))
+
+    def rows_of(self, rank: int):
+        """Global row indices held by `rank`, in strip order (only rows < height)."""
+        rows = []
+        for b in self.bands_of(rank):
+            rows.extend(range(b * self.band_rows, min((b + 1) * self.band_rows, self.height)))
+        return rows
+
+
+def reassemble_numpy(plan: BandPlan, strips) -> np.ndarray:
+    """strips[rank] = (strip_rows, width, 4) uint8 -> (height, width, 4)."""
+    out = np.zeros((plan.height, plan.width, 4), dtype=np.uint8)
+    for rank in range(plan.world):
+        for k, b in enumerate(plan.bands_of(rank)):
+            g0 = b * plan.band_rows
+            g1 = min(g0 + plan.band_rows, plan.height)
+            out[g0:g1] = np.asarray(strips[rank])[k * plan.band_rows:k * plan.band_rows + (g1 - g0)]
+    return out
+
+
+def reassemble_torch(plan: BandPlan, gathered):
+    """gathered: tensor (world, strip_rows, width, 4) on any device -> (height, width, 4).
+    Band b sits at gathered[b % world, (b // world)*band_rows : ...]: one permute + crop."""
+    w, bpr, br = plan.world, plan.bands_per_rank, plan.band_rows
+    g = gathered.view(w, bpr, br, plan.width, 4).permute(1, 0, 2, 3, 4).reshape(bpr * w * br, plan.width, 4)
+    return g[:plan.height].contiguous()
+
+
+def render_frame_distributed(plan: BandPlan, rank: int, render_rows, dist, strip, block=None):
+    """One frame over `plan.world` ranks.
+
+    render_rows(strip, band_rows, band_index, band_count) fills `strip` (a
+    (strip_rows, width, 4) uint8 torch tensor on this rank's device) with this
+    rank's bands.  The strips are then gathered into `block`
+    ((world, strip_rows, width, 4), rank 0 only) and rank 0 returns the
+    reassembled (height, width, 4) frame; other ranks return None.
+    """
+    render_rows(strip, plan.band_rows, rank, plan.world)
+    if plan.world == 1:
+        return reassemble_torch(plan, strip.unsqueeze(0))
+    dist.gather(strip, gather_list=list(block.unbind(0)) if rank == 0 else None, dst=0)
+    if rank != 0:
+        return None
+    return reassemble_torch(plan, block)

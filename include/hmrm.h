@@ -141,6 +141,15 @@ int hmrm_render_stats(const hmrm_scene *scene, const hmrm_camera *cam,
 int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam,
                    int32_t px, int32_t py, double pos[3], double dir[3], double *entry_d);
 
+/* Host-only (no GPU needed): the per-frame record the kernel receives for this
+ * camera -- the reference's per-frame set-up, main/hmap.cpp:661-672,:952-974.
+ * out25 = cam[3], upper_left[3], plane_right[3], plane_down[3], look[3], c0[3],
+ * c1[3], nudge, step_dist, grid_pow2, inv_grid_width.  `tables` (may be NULL;
+ * used for HMRM_SPHERICAL) receives 2*width + 2*height doubles: cos(ha) and
+ * sin(ha) per column, then sin(va) and cos(va) per row (Spherical.cpp:18-25). */
+int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params,
+                     int32_t map_w, int32_t map_h, double *out25, double *tables);
+
 /* Time of the most recent render kernel launch on this thread, measured with
  * HIP events on the launch stream (ms); <0 if none. Only valid after
  * hmrm_render / hmrm_render_stats, which synchronise. */

@@ -353,3 +353,23 @@ int oracle_max_threads(void) {
 	return 1;
 #endif
 }
+
+/* The per-frame record (hmap.cpp:661-672,:952-974) in the layout the product's
+ * hmrm_debug_frame test hook uses: cam[3], upper_left[3], plane_right[3],
+ * plane_down[3], look[3], c0[3], c1[3], nudge.  Fields a projection does not
+ * have are 0.  For spherical also: out[22..25] = hfov, vfov, ul_hang, ul_vang. */
+void oracle_frame_record(const oracle_cfg *c, double out[26]) {
+	plane_t pl;
+	v3 c0, c1;
+	int i = 0;
+	frame_setup(c, &pl, &c0, &c1);
+	out[i++] = pl.cam_pos.x; out[i++] = pl.cam_pos.y; out[i++] = pl.cam_pos.z;
+	out[i++] = pl.upper_left.x; out[i++] = pl.upper_left.y; out[i++] = pl.upper_left.z;
+	out[i++] = pl.plane_right.x; out[i++] = pl.plane_right.y; out[i++] = pl.plane_right.z;
+	out[i++] = pl.plane_down.x; out[i++] = pl.plane_down.y; out[i++] = pl.plane_down.z;
+	out[i++] = pl.look.x; out[i++] = pl.look.y; out[i++] = pl.look.z;
+	out[i++] = c0.x; out[i++] = c0.y; out[i++] = c0.z;
+	out[i++] = c1.x; out[i++] = c1.y; out[i++] = c1.z;
+	out[i++] = c->grid_width * 0.01;
+	out[i++] = pl.hfov; out[i++] = pl.vfov; out[i++] = pl.ul_hang; out[i++] = pl.ul_vang;
+}

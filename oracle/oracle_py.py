@@ -50,6 +50,8 @@ def load(opt: str = "O2"):
         lib.oracle_probe_ray.restype = None
         lib.oracle_probe_ray.argtypes = [C.POINTER(OracleCfg), C.c_int, C.c_int, C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.oracle_frame_record.restype = None
+        lib.oracle_frame_record.argtypes = [C.POINTER(OracleCfg), C.c_void_p]
         lib.oracle_degrees_to_rads.restype = C.c_double
         lib.oracle_degrees_to_rads.argtypes = [C.c_double]
         lib.oracle_max_threads.restype = C.c_int
@@ -104,6 +106,12 @@ def probe_ray(cfg: OracleCfg, px: int, py: int, opt="O2"):
     pos, dirv, d = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
     load(opt).oracle_probe_ray(C.byref(cfg), px, py, pos, dirv, C.byref(d))
     return np.array(pos[:]), np.array(dirv[:]), d.value
+
+
+def frame_record(cfg: OracleCfg, opt="O2") -> np.ndarray:
+    out = np.zeros(26, dtype=np.float64)
+    load(opt).oracle_frame_record(C.byref(cfg), out.ctypes.data)
+    return out
 
 
 def max_threads() -> int:

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Regenerates the committed fixtures under tests/golden/.
+
+  frames.npz      per test scene (tests/scenes.py): RGBA frame, per-ray step count,
+                  bits of distance().  Produced by the C ORACLE (oracle/), because
+                  the reference's render path can neither be built nor run here
+                  (SDL2/glm absent) and ships no golden data of its own.
+  png_decode.npz  small PNG/PNM files (bytes) and, for req_comp 0..4, the pixels
+                  the REFERENCE's own stb_image v2.27 decodes from them
+                  (oracle/_ref/libstb_ref.so, built from /root/reference/vendor).
+  png_encode.json sha256 + length of the files the REFERENCE's stb_image_write
+                  v1.16 writes for seeded test images.
+
+Run from the repo root in the build container:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import scenes  # noqa: E402
+import stb_ref  # noqa: E402
+from oracle import oracle_py as oracle  # noqa: E402
+
+
+# ----------------------------------------------------------------- frames ----
+def make_frames():
+    out = {}
+    for case in scenes.cases():
+        name, rgb, cmap, params, cam = scenes.build_case(case)
+        heights = oracle.update_heightmap(rgb, params)
+        cfg = oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0])
+        fb, total, capped, steps, entry = oracle.render(cfg, heights, cmap, per_pixel=True)
+        assert capped == 0
+        out[name + "/frame"] = fb
+        out[name + "/steps"] = steps.astype(np.uint32)
+        out[name + "/entry_bits"] = entry.view(np.uint64)
+    np.savez_compressed(os.path.join(HERE, "frames.npz"), **out)
+    print("frames.npz:", len(out) // 3, "scenes")
+
+
+# ------------------------------------------------------------ PNG fixtures ----
+def _chunk(tag, data):
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+
+def _paeth(a, b, c):
+    p = a + b - c
+    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+    return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+
+def _filter_rows(rows, bpp, rng):
+    """rows: list of bytes objects (packed scanlines); picks a random filter per row."""
+    out = bytearray()
+    prev = bytes(len(rows[0])) if rows else b""
+    for row in rows:
+        ft = int(rng.randint(0, 5))
+        out.append(ft)
+        for i, v in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            pred = (0, a, b, (a + b) >> 1, _paeth(a, b, c))[ft]
+            out.append((v - pred) & 255)
+        prev = row
+    return bytes(out)
+
+
+def _pack_rows(samples, depth):
+    """samples: H x (W*channels) integer array -> list of packed scanlines."""
+    rows = []
+    for r in samples:
+        if depth == 8:
+            rows.append(bytes(int(v) for v in r))
+        elif depth == 16:
+            rows.append(b"".join(struct.pack(">H", int(v)) for v in r))
+        else:
+            per = 8 // depth
+            buf = bytearray((len(r) + per - 1) // per)
+            for i, v in enumerate(r):
+                buf[i // per] |= (int(v) & ((1 << depth) - 1)) << (8 - depth * (i % per + 1))
+            rows.append(bytes(buf))
+    return rows
+
+
+def make_png(w, h, color, depth, rng, interlace=False, palette=None, trns=None, level=6):
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color]
+    maxv = (1 << depth) - 1 if color != 3 else (len(palette) // 3 - 1)
+    samples = rng.randint(0, maxv + 1, size=(h, w, channels))
+    bpp = max(1, channels * depth // 8)
+    raw = b""
+    if not interlace:
+        raw = _filter_rows(_pack_rows(samples.reshape(h, w * channels), depth), bpp, rng)
+    else:
+        for xo, yo, xs, ys in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = samples[yo::ys, xo::xs]
+            if sub.shape[0] == 0 or sub.shape[1] == 0:
+                continue
+            raw += _filter_rows(_pack_rows(sub.reshape(sub.shape[0], -1), depth), bpp, rng)
+    png = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, int(interlace)))
+    if palette is not None:
+        png += _chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        png += _chunk(b"tRNS", bytes(trns))
+    png += _chunk(b"tEXt", b"Comment\x00fixture")  # ancillary chunk must be skipped
+    z = zlib.compress(raw, level)
+    half = len(z) // 2
+    png += _chunk(b"IDAT", z[:half]) + _chunk(b"IDAT", z[half:])  # split IDAT
+    png += _chunk(b"IEND", b"")
+    return png
+
+
+def png_fixture_files():
+    rng = np.random.RandomState(1234)
+    files = {}
+    for depth in (1, 2, 4, 8, 16):
+        files[f"grey{depth}"] = make_png(13, 7, 0, depth, rng)
+        files[f"grey{depth}_i"] = make_png(13, 7, 0, depth, rng, interlace=True)
+    for depth in (8, 16):
+        files[f"rgb{depth}"] = make_png(11, 9, 2, depth, rng)
+        files[f"rgb{depth}_i"] = make_png(11, 9, 2, depth, rng, interlace=True)
+        files[f"ga{depth}"] = make_png(9, 5, 4, depth, rng)
+        files[f"rgba{depth}"] = make_png(10, 6, 6, depth, rng)
+        files[f"rgba{depth}_i"] = make_png(10, 6, 6, depth, rng, interlace=True)
+    pal = list(rng.randint(0, 256, size=16 * 3))
+    for depth in (1, 2, 4, 8):
+        n = min(16, 1 << depth)
+        files[f"pal{depth}"] = make_png(12, 8, 3, depth, rng, palette=pal[:n * 3])
+        files[f"pal{depth}_trns"] = make_png(12, 8, 3, depth, rng, palette=pal[:n * 3],
+                                             trns=list(rng.randint(0, 256, size=max(1, n // 2))))
+    files["pal4_i"] = make_png(12, 8, 3, 4, rng, interlace=True, palette=pal)
+    # colour-key transparency on grey / RGB
+    files["grey8_key"] = make_png(16, 4, 0, 8, rng, trns=[0, 5])
+    files["grey2_key"] = make_png(16, 4, 0, 2, rng, trns=[0, 2])
+    files["grey16_key"] = make_png(6, 6, 0, 16, rng, trns=[0x12, 0x34])
+    files["rgb8_key"] = make_png(5, 5, 2, 8, rng, trns=[0, 1, 0, 2, 0, 3])
+    files["one_pixel"] = make_png(1, 1, 2, 8, rng)
+    files["wide_stored"] = make_png(70, 3, 6, 8, rng, level=0)  # stored (BTYPE 0) deflate blocks
+    # PNM
+    files["p6"] = b"P6\n# comment\n7 5\n255\n" + bytes(rng.randint(0, 256, size=7 * 5 * 3).astype(np.uint8))
+    files["p5"] = b"P5 6 4 255\n" + bytes(rng.randint(0, 256, size=6 * 4).astype(np.uint8))
+    files["p6_16"] = b"P6\n3 2\n65535\n" + bytes(rng.randint(0, 256, size=3 * 2 * 3 * 2).astype(np.uint8))
+    return files
+
+
+def make_png_decode(ref):
+    files = png_fixture_files()
+    out = {}
+    for name, data in files.items():
+        out[name + "/bytes"] = np.frombuffer(data, dtype=np.uint8)
+        for req in range(5):
+            if name == "p6_16" and req not in (0, 3):
+                continue  # stb v2.27 mangles 16-bit PNM under channel conversion; not offered
+            arr, n = ref.load(data, req)
+            assert arr is not None, (name, req, n)
+            out[f"{name}/req{req}"] = arr
+            out[f"{name}/n{req}"] = np.array([n], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "png_decode.npz"), **out)
+    print("png_decode.npz:", len(files), "files")
+
+
+def encode_test_images():
+    rng = np.random.RandomState(99)
+    imgs = {}
+    imgs["noise_rgba"] = rng.randint(0, 256, size=(37, 53, 4)).astype(np.uint8)
+    g = np.add.outer(np.arange(64), np.arange(96)).astype(np.uint8)
+    imgs["gradient_rgb"] = np.stack([g, g // 2, 255 - g], axis=2)
+    imgs["flat_rgba"] = np.full((20, 30, 4), 77, dtype=np.uint8)
+    imgs["grey1"] = rng.randint(0, 4, size=(25, 40, 1)).astype(np.uint8) * 60
+    imgs["ga2"] = rng.randint(0, 256, size=(9, 9, 2)).astype(np.uint8)
+    imgs["tiny"] = rng.randint(0, 256, size=(1, 1, 4)).astype(np.uint8)
+    big = np.zeros((120, 200, 4), dtype=np.uint8)
+    big[:, :, 0] = (np.arange(200)[None, :] * 3) & 255
+    big[:, :, 1] = (np.arange(120)[:, None] * 5) & 255
+    big[40:80, 50:150, 2] = rng.randint(0, 256, size=(40, 100))
+    big[:, :, 3] = 255
+    imgs["frame_like"] = big
+    # a real frame from the oracle
+    case = scenes.cases()[0]
+    name, rgb, cmap, params, cam = scenes.build_case(case)
+    heights = oracle.update_heightmap(rgb, params)
+    fb, *_ = oracle.render(oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0]), heights, cmap)
+    imgs["oracle_frame"] = fb
+    return imgs
+
+
+def make_png_encode(ref):
+    out = {}
+    for name, img in encode_test_images().items():
+        data = ref.write_png(img)
+        out[name] = {"sha256": hashlib.sha256(data).hexdigest(), "length": len(data)}
+    with open(os.path.join(HERE, "png_encode.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("png_encode.json:", len(out), "images")
+
+
+if __name__ == "__main__":
+    make_frames()
+    ref = stb_ref.load()
+    if ref is None:
+        print("oracle/_ref/libstb_ref.so missing: run `make -C oracle` where /root/reference exists")
+        sys.exit(1)
+    make_png_decode(ref)
+    make_png_encode(ref)

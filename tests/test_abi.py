@@ -1,0 +1,61 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/hmrm.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "hmrm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(hmrm_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported(hmrm):
+    declared = _declared_functions()
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(hmrm.LIB_PATH)
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, f"declared in include/hmrm.h but not exported: {missing}"
+    # and the binding binds exactly the declared set
+    assert sorted(hmrm.EXPORTED_SYMBOLS) == declared
+
+
+def test_abi_version_and_error_string(hmrm):
+    from importlib import import_module
+    lib = import_module("heightmap-ray-marcher_amd.lib").lib
+    assert lib.hmrm_abi_version() == 1
+    assert isinstance(hmrm.last_error(), str)
+
+
+def test_no_cpu_fallback_without_gpu(hmrm):
+    """On a box without a GPU every render entry point fails loudly (HMRM_E_DEVICE)."""
+    try:
+        n = hmrm.device_count()
+    except hmrm.HmrmError as e:
+        assert e.code == hmrm.HMRM_E_DEVICE
+        n = 0
+    if n > 0:
+        pytest.skip("GPU present")
+    import numpy as np
+    rgb = np.zeros((4, 4, 3), dtype=np.uint8)
+    cmap = np.zeros((4, 4, 4), dtype=np.uint8)
+    with pytest.raises(hmrm.HmrmError) as e:
+        hmrm.Scene(rgb, cmap, hmrm.SceneParams.make())
+    assert e.value.code == hmrm.HMRM_E_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package may import, link or open it."""
+    pkg = os.path.join(ROOT, "heightmap-ray-marcher_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                code = re.sub(r"//[^\n]*|#[^\n]*", "", text)  # comments may mention it, code may not
+                hit = re.search(r"liboracle|oracle_py|from\s+oracle|import\s+oracle|oracle/|hmrm_oracle", code)
+                assert not hit, (os.path.join(dirpath, f), hit.group(0))

@@ -1,0 +1,140 @@
+"""Image decode / encode rows (L1 data prep in, L0 PNG out), CPU only.
+
+These rows ARE pinned against the reference: tests/golden/png_decode.npz and
+png_encode.json hold what the reference's own vendored stb (v2.27 / v1.16,
+built from /root/reference/vendor as oracle/_ref) produces, and where that
+build is present the comparison is also made live.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLDEN)
+
+
+def _decode_fixture():
+    return np.load(os.path.join(GOLDEN, "png_decode.npz"))
+
+
+def _names(data):
+    return sorted({k.split("/")[0] for k in data.files})
+
+
+def test_decode_matches_reference_stb_golden(hmrm):
+    """stbi_load(path,&w,&h,&n,req_comp) (hmap.cpp:320-321,341-342) for req_comp 0..4."""
+    data = _decode_fixture()
+    checked = 0
+    for name in _names(data):
+        blob = data[name + "/bytes"].tobytes()
+        for req in range(5):
+            key = f"{name}/req{req}"
+            if key not in data.files:
+                continue
+            arr, n = hmrm.image_load_memory(blob, req)
+            assert n == int(data[f"{name}/n{req}"][0]), (name, req)
+            assert arr.shape == data[key].shape, (name, req)
+            assert np.array_equal(arr, data[key]), (name, req)
+            checked += 1
+    assert checked > 150
+
+
+def test_decode_matches_reference_stb_live(hmrm, stb_ref):
+    if stb_ref is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here); golden vectors cover it")
+    import make_golden
+    for name, blob in make_golden.png_fixture_files().items():
+        for req in range(5):
+            exp, n = stb_ref.load(blob, req)
+            if name == "p6_16" and req not in (0, 3):
+                with pytest.raises(hmrm.HmrmError):
+                    hmrm.image_load_memory(blob, req)
+                continue
+            arr, n2 = hmrm.image_load_memory(blob, req)
+            assert n2 == n and np.array_equal(arr, exp), (name, req)
+
+
+def test_decode_large_random_png_roundtrip(hmrm, stb_ref):
+    """A 300x200 map-like image through zlib level 9 (dynamic Huffman, long matches)."""
+    import struct
+    import zlib
+    rng = np.random.RandomState(5)
+    img = np.cumsum(rng.randint(-3, 4, size=(200, 300, 3)), axis=1).astype(np.uint8)
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(200))
+
+    def chunk(tag, d):
+        return struct.pack(">I", len(d)) + tag + d + struct.pack(">I", zlib.crc32(tag + d) & 0xFFFFFFFF)
+
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 300, 200, 8, 2, 0, 0, 0))
+           + chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b""))
+    arr, n = hmrm.image_load_memory(png, 3)
+    assert n == 3 and np.array_equal(arr, img)
+    arr4, _ = hmrm.image_load_memory(png, 4)
+    assert np.array_equal(arr4[:, :, :3], img) and (arr4[:, :, 3] == 255).all()
+    if stb_ref is not None:
+        exp, _ = stb_ref.load(png, 4)
+        assert np.array_equal(arr4, exp)
+
+
+def test_decode_errors(hmrm, tmp_path):
+    with pytest.raises(hmrm.HmrmError) as e:
+        hmrm.image_load(str(tmp_path / "missing.png"), 3)
+    assert e.value.code == hmrm.HMRM_E_IO
+    for blob in (b"", b"GIF89a....", b"\xff\xd8\xff\xe0" + b"\0" * 32, b"\x89PNG\r\n\x1a\n" + b"\0" * 40,
+                 b"P6\n4 4\n255\n"[:5]):
+        with pytest.raises(hmrm.HmrmError) as e:
+            hmrm.image_load_memory(blob, 3)
+        assert e.value.code == hmrm.HMRM_E_IMAGE
+    # truncated IDAT stream
+    data = _decode_fixture()
+    blob = data["rgb8/bytes"].tobytes()
+    with pytest.raises(hmrm.HmrmError):
+        hmrm.image_load_memory(blob[: len(blob) // 2], 3)
+
+
+def test_png_encode_matches_reference_stb_golden(hmrm):
+    """SavePNG / stbi_write_png (hmap.cpp:157-160): byte-identical files."""
+    import make_golden
+    with open(os.path.join(GOLDEN, "png_encode.json")) as f:
+        golden = json.load(f)
+    imgs = make_golden.encode_test_images()
+    assert set(imgs) == set(golden)
+    for name, img in imgs.items():
+        data = hmrm.png_encode(img)
+        assert len(data) == golden[name]["length"], name
+        assert hashlib.sha256(data).hexdigest() == golden[name]["sha256"], name
+
+
+def test_png_encode_matches_reference_stb_live(hmrm, stb_ref):
+    if stb_ref is None:
+        pytest.skip("oracle/_ref not built; golden hashes cover it")
+    rng = np.random.RandomState(3)
+    for (h, w, c) in ((1, 1, 1), (2, 3, 3), (31, 17, 4), (64, 64, 4), (5, 300, 2), (200, 150, 3)):
+        for kind in ("noise", "smooth", "flat"):
+            if kind == "noise":
+                img = rng.randint(0, 256, size=(h, w, c)).astype(np.uint8)
+            elif kind == "smooth":
+                img = (np.add.outer(np.arange(h) * 2, np.arange(w) * 3)[:, :, None] + np.arange(c) * 40).astype(np.uint8)
+            else:
+                img = np.full((h, w, c), 200, dtype=np.uint8)
+            assert hmrm.png_encode(img) == stb_ref.write_png(img), (h, w, c, kind)
+
+
+def test_png_roundtrip_and_files(hmrm, tmp_path):
+    rng = np.random.RandomState(8)
+    img = rng.randint(0, 256, size=(40, 50, 4)).astype(np.uint8)
+    p = str(tmp_path / "a.png")
+    hmrm.write_png(p, img)
+    back, n = hmrm.image_load(p, 4)
+    assert n == 4 and np.array_equal(back, img)
+    q = str(tmp_path / "a.ppm")
+    hmrm.write_ppm(q, img)
+    back3, n3 = hmrm.image_load(q, 3)
+    assert n3 == 3 and np.array_equal(back3, img[:, :, :3])
+    with pytest.raises(hmrm.HmrmError) as e:
+        hmrm.write_png(str(tmp_path / "no_such_dir" / "x.png"), img)
+    assert e.value.code == hmrm.HMRM_E_IO

@@ -1,0 +1,227 @@
+"""GPU parity tests: the HIP path through the C ABI against the CPU oracle.
+
+Bar: bit-exact (integer colour lookups AND every fp64 intermediate that is
+observable: heights, distance(), per-ray step counts, ray directions).
+Sizes the oracle finishes in seconds are compared directly; BASELINE.json's
+full sizes are covered by row-subsampled oracle comparison and by
+size-independent properties (determinism, strips == full frame, counters add up).
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def gpu(hmrm):
+    assert hmrm.device_count() >= 1, "no GPU visible: these tests must run on the MI355X box"
+    hmrm.set_device(0)
+    return hmrm
+
+
+@pytest.mark.parametrize("case", scenes.cases(), ids=scenes.case_ids())
+def test_frame_steps_and_distance_bit_exact(gpu, oracle, case):
+    name, rgb, cmap, params, cam = scenes.build_case(case)
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    assert np.array_equal(_bits(scene.read_heights()), _bits(heights)), "UpdateHeightmap (hmap.cpp:171-191)"
+    cfg = oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0])
+    ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True)
+    fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
+    assert np.array_equal(_bits(entry), _bits(oentry)), "distance() (AABB.cpp:49-77)"
+    assert np.array_equal(steps.astype(np.int64), osteps), "per-ray step count (hmap.cpp:1000-1038)"
+    assert np.array_equal(fb, ofb), "frame (hmap.cpp:978-1058)"
+    assert (st.rays, st.steps, st.capped) == (cam.width * cam.height, total, 0)
+    assert st.hits <= st.rays
+    # the un-instrumented kernel writes the same pixels
+    assert np.array_equal(scene.render(cam), ofb)
+    scene.close()
+
+
+def test_golden_frames(gpu):
+    data = np.load(os.path.join(GOLDEN, "frames.npz"))
+    for case in scenes.cases():
+        name, rgb, cmap, params, cam = scenes.build_case(case)
+        scene = gpu.Scene(rgb, cmap, params)
+        fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
+        assert np.array_equal(fb, data[name + "/frame"]), name
+        assert np.array_equal(steps, data[name + "/steps"]), name
+        assert np.array_equal(_bits(entry), data[name + "/entry_bits"]), name
+        scene.close()
+
+
+@pytest.mark.parametrize("case", scenes.cases()[:9], ids=scenes.case_ids()[:9])
+def test_ray_generation_bit_exact(gpu, oracle, case):
+    """ImagePlane::GetRay on the device (incl. device sqrt and division) vs the oracle."""
+    name, rgb, cmap, params, cam = scenes.build_case(case)
+    scene = gpu.Scene(rgb, cmap, params)
+    cfg = oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0])
+    rng = np.random.RandomState(3)
+    pix = [(0, 0), (cam.width - 1, 0), (0, cam.height - 1), (cam.width - 1, cam.height - 1)]
+    pix += [(int(rng.randint(cam.width)), int(rng.randint(cam.height))) for _ in range(24)]
+    for px, py in pix:
+        pos, d, dist = scene.debug_ray(cam, px, py)
+        opos, od, odist = oracle.probe_ray(cfg, px, py)
+        assert np.array_equal(_bits(pos), _bits(opos)) and np.array_equal(_bits(d), _bits(od)), (px, py)
+        assert _bits(dist) == _bits(odist), (px, py)
+    scene.close()
+
+
+def test_scene_update_recomputes_heights(gpu, oracle):
+    rgb, cmap = scenes.small_maps(48, 40, 77, color_heights=True)
+    p1 = gpu.SceneParams.make(0.0, 5.0, grid_width=0.5)
+    p2 = gpu.SceneParams.make(-1.0, 9.0, lum=(0.2, 0.7, 0.1), grid_width=0.25)
+    cam = gpu.Camera.make(width=64, height=48, hfov=gpu.degrees_to_rads(80), hang=gpu.degrees_to_rads(-45),
+                          vang=gpu.degrees_to_rads(118), pos=(-4.0, 4.0, 14.0), step_dist=0.125, bg=(3, 2, 1))
+    scene = gpu.Scene(rgb, cmap, p1)
+    for p in (p1, p2, p1):
+        scene.update(p)
+        heights = oracle.update_heightmap(rgb, p)
+        assert np.array_equal(_bits(scene.read_heights()), _bits(heights))
+        ofb, *_ = oracle.render(oracle.make_cfg(cam, p, 48, 40), heights, cmap)
+        assert np.array_equal(scene.render(cam), ofb)
+    scene.close()
+
+
+def test_row_strips_and_cyclic_bands_equal_full_frame(gpu):
+    """Multi-GPU partitioning on one device: strips / bands reassemble to the frame."""
+    import torch
+    rgb, cmap = gpu.synth.synth_maps(256)
+    wl = gpu.synth.WORKLOADS["C1"]
+    params = wl.scene_params()
+    scene = gpu.Scene(rgb, cmap, params)
+    for proj in (1, 2, 3):
+        cam = wl.camera()
+        cam.projection = proj
+        cam.width, cam.height = 203, 117  # ragged: not a multiple of the 16x16 tile
+        cam.ortho_width = 1.5
+        full = scene.render(cam)
+        # contiguous strips
+        parts = []
+        for r0, r1 in ((0, 40), (40, 41), (41, 117)):
+            buf = torch.zeros((r1 - r0, cam.width, 4), dtype=torch.uint8, device="cuda")
+            scene.render_rows_device(cam, buf.data_ptr(), cam.width * 4, r0, r1,
+                                     stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            parts.append(buf.cpu().numpy())
+        assert np.array_equal(np.concatenate(parts, 0), full)
+        # cyclic bands of 16 rows over 3 "ranks"
+        band, n = 16, 3
+        out = np.zeros_like(full)
+        for rank in range(n):
+            rows = gpu.band_local_rows(cam.height, band, rank, n)
+            buf = torch.zeros((rows, cam.width, 4), dtype=torch.uint8, device="cuda")
+            scene.render_rows_device(cam, buf.data_ptr(), cam.width * 4, band_rows=band, band_index=rank,
+                                     band_count=n, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            host = buf.cpu().numpy()
+            for k in range(rows // band):
+                g0 = (rank + k * n) * band
+                g1 = min(g0 + band, cam.height)
+                if g0 < cam.height:
+                    out[g0:g1] = host[k * band:k * band + (g1 - g0)]
+        assert np.array_equal(out, full)
+    scene.close()
+
+
+@pytest.mark.parametrize("wl_name", ["C1", "C2"])
+def test_baseline_config_full_frame_vs_oracle(gpu, oracle, wl_name):
+    """BASELINE configs small enough for the oracle to render completely (C2: ~2 M rays)."""
+    wl = gpu.synth.WORKLOADS[wl_name]
+    rgb, cmap = gpu.synth.synth_maps(wl.map_size)
+    params, cam = wl.scene_params(), wl.camera()
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    ofb, total, capped, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap)
+    fb, st, _, _ = scene.render_stats(cam)
+    assert np.array_equal(fb, ofb)
+    assert st.steps == total and capped == 0 and st.capped == 0
+    scene.close()
+
+
+@pytest.mark.parametrize("wl_name", ["C3", "C3h", "C5"])
+def test_baseline_config_full_size_subsampled_and_properties(gpu, oracle, wl_name):
+    """Full BASELINE size (3840x2160 over 4096^2): every 24th row against the oracle, plus
+    size-independent properties: determinism, instrumented == plain kernel, counters add up."""
+    wl = gpu.synth.WORKLOADS[wl_name]
+    rgb, cmap = gpu.synth.synth_maps(wl.map_size)
+    params, cam = wl.scene_params(), wl.camera()
+    scene = gpu.Scene(rgb, cmap, params)
+    fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
+    fb2 = scene.render(cam)
+    assert np.array_equal(fb, fb2), "instrumented and plain kernels differ"
+    assert np.array_equal(scene.render(cam), fb2), "render is not deterministic"
+    assert int(steps.astype(np.int64).sum()) == st.steps and st.rays == cam.width * cam.height
+    assert (fb[:, :, 3] == 255).all()
+    heights = oracle.update_heightmap(rgb, params)
+    assert np.array_equal(_bits(scene.read_heights()), _bits(heights))
+    ofb = np.zeros_like(fb)
+    cfg = oracle.make_cfg(cam, params, wl.map_size, wl.map_size)
+    stride = 24
+    ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True, row_stride=stride)
+    assert capped == 0
+    rows = slice(0, cam.height, stride)
+    assert np.array_equal(fb[rows], ofb[rows])
+    assert np.array_equal(steps[rows].astype(np.int64), osteps[rows])
+    assert np.array_equal(_bits(entry[rows]), _bits(oentry[rows]))
+    scene.close()
+
+
+def test_step_cap_is_reported_not_silent(gpu, oracle):
+    """A vertical upward ray over a non-hitting cell never leaves the reference's while(true)
+    (hmap.cpp:1000-1038).  The kernel stops at the cap, shades a miss and says so."""
+    rgb = np.zeros((8, 8, 3), dtype=np.uint8)
+    cmap = np.full((8, 8, 4), 255, dtype=np.uint8)
+    params = gpu.SceneParams.make(0.0, 4.0, grid_width=1.0)
+    # orthographic straight UP from below the box: dir = (0,0,1) after the float round trip
+    cam = gpu.Camera.make(width=4, height=4, projection=3, hang=0.0, vang=0.0, pos=(4.0, -4.0, -3.0),
+                          ortho_width=0.5, step_dist=0.0, bg=(9, 8, 7))
+    os.environ["HMRM_STEP_CAP"] = "1000"
+    try:
+        scene = gpu.Scene(rgb, cmap, params)
+        fb, st, steps, _ = scene.render_stats(cam, per_pixel=True, allow_capped=True)
+        assert st.capped == 16 and (steps == 1000).all()
+        with pytest.raises(gpu.HmrmError) as e:
+            scene.render(cam)
+        assert e.value.code == gpu.HMRM_E_NOTERM
+        heights = oracle.update_heightmap(rgb, params)
+        ofb, total, capped, *_ = oracle.render(oracle.make_cfg(cam, params, 8, 8, step_cap=1000), heights, cmap)
+        assert capped == 16 and np.array_equal(fb, ofb)
+        scene.close()
+    finally:
+        del os.environ["HMRM_STEP_CAP"]
+
+
+def test_cli_end_to_end(gpu, oracle, tmp_path):
+    """hmap <config>: reference-format config file -> PNG and PPM with the oracle's pixels."""
+    wl = gpu.synth.WORKLOADS["C1"]
+    rgb, cmap = gpu.synth.synth_maps(wl.map_size)
+    hp, cp = str(tmp_path / "h.ppm"), str(tmp_path / "c.png")
+    gpu.write_ppm(hp, rgb)
+    gpu.write_png(cp, cmap)
+    params, cam = wl.scene_params(), wl.camera()
+    heights = oracle.update_heightmap(rgb, params)
+    ofb, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap)
+    exe = os.path.join(os.path.dirname(gpu.LIB_PATH), "hmap")
+    for ext in ("png", "ppm"):
+        outp = str(tmp_path / f"frame.{ext}")
+        cfgp = tmp_path / f"c_{ext}.txt"
+        cfgp.write_text(gpu.synth.config_text(wl, hp, cp, outp))
+        r = subprocess.run([exe, str(cfgp)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert f"Saved screenshot at {outp}" in r.stdout and r.stdout.startswith("resolution 320 240\n")
+        img, n = gpu.image_load(outp, 4)
+        assert np.array_equal(img, ofb)
+        if ext == "png":
+            assert open(outp, "rb").read() == gpu.png_encode(ofb)
