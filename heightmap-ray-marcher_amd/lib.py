@@ -75,6 +75,15 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C heightmap-ray-marcher_amd/csrc` (there is no fallback path)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and must be
+    # the first to load it, otherwise torch later finds "No HIP GPUs" next to the system
+    # runtime this library would pull in.  Loading torch first makes libhmrm.so resolve the
+    # same, already-loaded runtime (same SONAME).  The C++ CLI uses the system runtime alone.
+    if os.environ.get("HMRM_NO_TORCH_PRELOAD", "") == "":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     u8p, dp, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.POINTER(C.c_uint32)
     vp, i32 = C.c_void_p, C.c_int32
