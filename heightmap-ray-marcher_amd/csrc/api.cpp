@@ -56,9 +56,11 @@ struct hmrm_scene {
 	uint32_t *d_cmap = nullptr; // W*H    colormap_buf as packed RGBA (hmap.cpp:59)
 	double *d_thr = nullptr;    // W*H    heightmap_buf[i] + min_height
 	double thr_max = 0.0;
+	double *d_mip[3] = {nullptr, nullptr, nullptr}; // max pyramid over d_thr, block edge 4/16/64 cells
+	int32_t mip_w[3] = {0, 0, 0}, mip_h[3] = {0, 0, 0};
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	unsigned long long *d_counters = nullptr; // 4 x u64: steps, hits, capped, max key
+	unsigned long long *d_counters = nullptr; // 8 x u64: steps, hits, capped, max key, 4 x traversal diagnostics
 	// per-render scratch, grown on demand (a scene is used by one host thread at a time)
 	uint32_t *d_frame = nullptr;
 	size_t frame_px = 0;
@@ -76,6 +78,21 @@ struct hmrm_config {
 };
 
 namespace {
+
+// Kernel variant: "leap" (default; speculative groups + exact leaps), "group"
+// (speculative groups only), "simple" (the literal one-step-at-a-time loop, kept for A/B
+// runs and as an in-library cross-check).  All three produce identical pixels and counts.
+hipError_t launch_variant(const hmrm::DevFrame &f, const hmrm::RowMap &rows, const hmrm_scene *s,
+                          uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry,
+                          bool stats, hipStream_t stream) {
+	const char *k = getenv("HMRM_KERNEL");
+	if (k && strcmp(k, "simple") == 0)
+		return hmrm::launch_render(f, rows, s->d_thr, s->d_cmap, d_out, out_stride_px, s->d_counters, d_steps,
+		                           d_entry, stats, stream);
+	const bool leap = !(k && strcmp(k, "group") == 0);
+	return hmrm::launch_render_fast(f, rows, s->d_thr, s->d_cmap, d_out, out_stride_px, s->d_counters,
+	                                d_steps, d_entry, stats, leap, stream);
+}
 
 int ensure_frame(hmrm_scene *s, size_t px) {
 	if (px <= s->frame_px) return HMRM_OK;
@@ -161,6 +178,10 @@ int prepare_frame(hmrm_scene *s, const hmrm_camera *cam, hipStream_t stream, hmr
 	}
 	f->thr_max = s->thr_max;
 	f->step_cap = default_step_cap();
+	for (int l = 0; l < hmrm::kMipLevels; ++l) {
+		f->mip[l] = s->d_mip[l];
+		f->mip_w[l] = s->mip_w[l];
+	}
 	return HMRM_OK;
 }
 
@@ -170,6 +191,13 @@ int run_update_heights(hmrm_scene *s) {
 	HIP_TRY(hmrm::launch_prepare_heights(s->d_rgb, s->d_thr, n, s->params.lum_r, s->params.lum_g,
 	                                     s->params.lum_b, s->params.min_height, s->params.max_height,
 	                                     false, s->d_counters + 3, s->stream));
+	// max pyramid for the exact-leap traversal: level l from level l-1 (level 0 from thr)
+	for (int l = 0; l < hmrm::kMipLevels; ++l) {
+		const double *src = l == 0 ? s->d_thr : s->d_mip[l - 1];
+		const int sw = l == 0 ? s->map_w : s->mip_w[l - 1], sh = l == 0 ? s->map_h : s->mip_h[l - 1];
+		const int factor = 1 << (hmrm::kMipShift[l] - (l == 0 ? 0 : hmrm::kMipShift[l - 1]));
+		HIP_TRY(hmrm::launch_build_mip(src, sw, sh, s->d_mip[l], s->mip_w[l], s->mip_h[l], factor, s->stream));
+	}
 	unsigned long long key = 0;
 	HIP_TRY(hipMemcpyAsync(&key, s->d_counters + 3, sizeof key, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -219,8 +247,14 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 		HIP_TRY(hipMalloc((void **)&s->d_rgb, n * 3));
 		HIP_TRY(hipMalloc((void **)&s->d_cmap, n * 4));
 		HIP_TRY(hipMalloc((void **)&s->d_thr, n * sizeof(double)));
-		HIP_TRY(hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned long long)));
-		HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), s->stream));
+		for (int l = 0; l < hmrm::kMipLevels; ++l) {
+			const int edge = 1 << hmrm::kMipShift[l];
+			s->mip_w[l] = (map_w + edge - 1) / edge;
+			s->mip_h[l] = (map_h + edge - 1) / edge;
+			HIP_TRY(hipMalloc((void **)&s->d_mip[l], (size_t)s->mip_w[l] * s->mip_h[l] * sizeof(double)));
+		}
+		HIP_TRY(hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long)));
+		HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->stream));
 		HIP_TRY(hipMemcpyAsync(s->d_rgb, height_rgb, n * 3, hipMemcpyHostToDevice, s->stream));
 		HIP_TRY(hipMemcpyAsync(s->d_cmap, color_rgba, n * 4, hipMemcpyHostToDevice, s->stream));
 		return run_update_heights(s);
@@ -250,6 +284,8 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (s->d_rgb) (void)hipFree(s->d_rgb);
 	if (s->d_cmap) (void)hipFree(s->d_cmap);
 	if (s->d_thr) (void)hipFree(s->d_thr);
+	for (int l = 0; l < 3; ++l)
+		if (s->d_mip[l]) (void)hipFree(s->d_mip[l]);
 	if (s->d_counters) (void)hipFree(s->d_counters);
 	if (s->d_frame) (void)hipFree(s->d_frame);
 	if (s->d_tables) (void)hipFree(s->d_tables);
@@ -294,14 +330,14 @@ static int render_common(hmrm_scene *s, const hmrm_camera *cam, uint8_t *rgba, s
 	if ((rc = prepare_frame(s, cam, s->stream, &f))) return rc;
 	hmrm::RowMap rows{0, cam->height, 0, 0, 1};
 	HIP_TRY(hipMemsetAsync(s->d_counters, 0, 3 * sizeof(unsigned long long), s->stream));
+	HIP_TRY(hipMemsetAsync(s->d_counters + 4, 0, 4 * sizeof(unsigned long long), s->stream));
 	HIP_TRY(hipEventRecord(s->ev0, s->stream));
-	HIP_TRY(hmrm::launch_render(f, rows, s->d_thr, s->d_cmap, s->d_frame, (int64_t)W, s->d_counters,
-	                            want_stats ? s->d_steps : nullptr, want_stats ? s->d_entry : nullptr,
-	                            want_stats, s->stream));
+	HIP_TRY(launch_variant(f, rows, s, s->d_frame, (int64_t)W, want_stats ? s->d_steps : nullptr,
+	                       want_stats ? s->d_entry : nullptr, want_stats, s->stream));
 	HIP_TRY(hipEventRecord(s->ev1, s->stream));
 	HIP_TRY(hipMemcpy2DAsync(rgba, stride_bytes, s->d_frame, W * 4, W * 4, H, hipMemcpyDeviceToHost,
 	                         s->stream));
-	unsigned long long counters[3] = {0, 0, 0};
+	unsigned long long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	HIP_TRY(hipMemcpyAsync(counters, s->d_counters, sizeof counters, hipMemcpyDeviceToHost, s->stream));
 	if (want_stats && steps_pp)
 		HIP_TRY(hipMemcpyAsync(steps_pp, s->d_steps, W * H * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -316,6 +352,10 @@ static int render_common(hmrm_scene *s, const hmrm_camera *cam, uint8_t *rgba, s
 		stats->steps = counters[0];
 		stats->hits = counters[1];
 		stats->capped = counters[2];
+		stats->leap_attempts = counters[4];
+		stats->leaps = counters[5];
+		stats->groups = counters[6];
+		stats->leaped_steps = counters[7];
 	}
 	if (counters[2]) {
 		char buf[160];
@@ -372,8 +412,8 @@ int hmrm_render_rows_device(const hmrm_scene *scene, const hmrm_camera *cam, voi
 	hipStream_t stream = (hipStream_t)hip_stream;
 	hmrm::DevFrame f;
 	if ((rc = prepare_frame(s, cam, stream, &f))) return rc;
-	HIP_TRY(hmrm::launch_render(f, rows, s->d_thr, s->d_cmap, (uint32_t *)d_rgba,
-	                            (int64_t)(stride_bytes / 4), s->d_counters, nullptr, nullptr, false, stream));
+	HIP_TRY(launch_variant(f, rows, s, (uint32_t *)d_rgba, (int64_t)(stride_bytes / 4), nullptr, nullptr,
+	                       false, stream));
 	return HMRM_OK;
 }
 
@@ -395,8 +435,7 @@ double hmrm_bench_kernel_ms(const hmrm_scene *scene, const hmrm_camera *cam, int
 		hmrm::RowMap rows{0, cam->height, 0, 0, 1};
 		HIP_TRY(hipEventRecord(s->ev0, s->stream));
 		for (int i = 0; i < iters; ++i)
-			HIP_TRY(hmrm::launch_render(f, rows, s->d_thr, s->d_cmap, s->d_frame, (int64_t)W,
-			                            s->d_counters, nullptr, nullptr, false, s->stream));
+			HIP_TRY(launch_variant(f, rows, s, s->d_frame, (int64_t)W, nullptr, nullptr, false, s->stream));
 		HIP_TRY(hipEventRecord(s->ev1, s->stream));
 		HIP_TRY(hipStreamSynchronize(s->stream));
 		float ms = 0.f;

@@ -136,7 +136,8 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min
 	int e = 0;
 	const double m = std::frexp(grid_width, &e);
 	f->grid_pow2 = (std::isfinite(grid_width) && m == 0.5 && e > -1000 && e < 1000) ? 1 : 0;
-	f->inv_grid_width = f->grid_pow2 ? 1.0 / grid_width : 0.0;
+	f->inv_grid_width = 1.0 / grid_width;
+	f->grid_mode = grid_width == 1.0 ? 0 : (f->grid_pow2 ? 1 : 2);
 }
 
 } // namespace hmrm

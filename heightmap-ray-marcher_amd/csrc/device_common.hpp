@@ -1,0 +1,158 @@
+// device_common.hpp -- device helpers shared by the render kernels: ray
+// generation (src/{Perspective,Spherical,Orthographic}.cpp GetRay), the slab test
+// (src/AABB.cpp:49-77), pixel packing (main/hmap.cpp:139-154) and the sky shade
+// (main/hmap.cpp:1041-1057).  Include only from .hip files compiled with
+// -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "frame.hpp"
+
+#pragma clang fp contract(off)
+
+namespace hmrm {
+
+// ----------------------------------------------------------------- render ----
+struct DevRay {
+	double px, py, pz;
+	double dx, dy, dz;
+};
+
+template <int PROJ>
+__device__ __forceinline__ DevRay make_ray(const DevFrame &f, int px, int py) {
+	DevRay r;
+	if (PROJ == 2) {
+		// Spherical.cpp:23-25; sin/cos come from the host tables
+		const double sva = f.row_sin_va[py], cva = f.row_cos_va[py];
+		const double cha = f.col_cos_ha[px], sha = f.col_sin_ha[px];
+		r.px = f.cam[0]; r.py = f.cam[1]; r.pz = f.cam[2];
+		r.dx = sva * cha;
+		r.dy = sva * sha;
+		r.dz = cva;
+	} else {
+		// hmap.cpp:985-988
+		const double w = (double)px / (double)(f.screen_w - 1);
+		const double h = (double)py / (double)(f.screen_h - 1);
+		// upper_left + w*plane_right + h*plane_down  (Perspective.cpp:27, Orthographic.cpp:20)
+		const double ox = (f.upper_left[0] + w * f.plane_right[0]) + h * f.plane_down[0];
+		const double oy = (f.upper_left[1] + w * f.plane_right[1]) + h * f.plane_down[1];
+		const double oz = (f.upper_left[2] + w * f.plane_right[2]) + h * f.plane_down[2];
+		if (PROJ == 1) {
+			const double vx = ox - f.cam[0], vy = oy - f.cam[1], vz = oz - f.cam[2];
+			// glm::normalize: v * (1 / sqrt(dot(v,v))), dot = (x*x + y*y) + z*z
+			const double tx = vx * vx, ty = vy * vy, tz = vz * vz;
+			const double inv = 1.0 / __builtin_sqrt((tx + ty) + tz);
+			r.px = f.cam[0]; r.py = f.cam[1]; r.pz = f.cam[2];
+			r.dx = vx * inv;
+			r.dy = vy * inv;
+			r.dz = vz * inv;
+		} else {
+			r.px = ox; r.py = oy; r.pz = oz;
+			r.dx = f.look[0]; r.dy = f.look[1]; r.dz = f.look[2];
+		}
+	}
+	return r;
+}
+
+// AABB.cpp:49-77, axis order x,y,z, same comparisons (NaN => every test false).
+__device__ __forceinline__ double slab_distance(const DevRay &r, const DevFrame &f) {
+	const double inf = __builtin_huge_val();
+	double lo = -inf, hi = inf;
+	const double ro[3] = {r.px, r.py, r.pz};
+	const double rd[3] = {r.dx, r.dy, r.dz};
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		double dim_lo = (f.c0[i] - ro[i]) / rd[i];
+		double dim_hi = (f.c1[i] - ro[i]) / rd[i];
+		if (dim_lo > dim_hi) {
+			const double t = dim_lo;
+			dim_lo = dim_hi;
+			dim_hi = t;
+		}
+		if (dim_hi < lo || dim_lo > hi) return inf;
+		if (dim_lo > lo) lo = dim_lo;
+		if (dim_hi < hi) hi = dim_hi;
+	}
+	return (lo > hi) ? inf : lo;
+}
+
+__device__ __forceinline__ uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b) {
+	return r | (g << 8) | (b << 16) | 0xff000000u; // bytes R,G,B,A=255 (hmap.cpp:150-153)
+}
+
+// Clamp<double>(v,0,255) then floor then (Uint8), hmap.cpp:1049-1051
+__device__ __forceinline__ uint32_t sky_channel(double v) {
+	if (v < 0.0) v = 0.0;
+	else if (v > 255.0) v = 255.0;
+	return (uint32_t)(int)__builtin_floor(v);
+}
+
+struct StatsOut {
+	unsigned long long *counters; // [0] steps [1] hits [2] capped
+	uint32_t *steps_per_pixel;    // screen_w*screen_h or null
+	double *entry_d;              // screen_w*screen_h or null
+};
+
+
+// Miss shade: hmap.cpp:1041-1057.
+__device__ __forceinline__ uint32_t shade_miss(const DevFrame &f, double dz) {
+	if (dz > 0.0) {
+		const double zz = dz * dz; // std::pow(z,2) == z*z under -std=c++98 (__builtin_powi)
+		const double r_ = 220.0 * zz + (double)f.bg[0];
+		const double g_ = 240.0 * zz + (double)f.bg[1];
+		const double b_ = 255.0 * dz + (double)f.bg[2];
+		return pack_rgba(sky_channel(r_), sky_channel(g_), sky_channel(b_));
+	}
+	return pack_rgba(f.bg[0], f.bg[1], f.bg[2]);
+}
+
+// Hit shade: hmap.cpp:1018-1031 (alpha 0 -> background colour).
+__device__ __forceinline__ uint32_t shade_hit(const DevFrame &f, uint32_t texel) {
+	return ((texel >> 24) == 0) ? pack_rgba(f.bg[0], f.bg[1], f.bg[2]) : (texel | 0xff000000u);
+}
+
+// Which pixel a lane owns: 16x16 pixel tile per workgroup, one 8x8 sub-tile per wave.
+struct PixelId {
+	int px, py, lrow;
+	bool live;
+};
+__device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap &rows, int tiles_x) {
+	const int tile = blockIdx.x;
+	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	PixelId p;
+	p.px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+	p.lrow = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	if (rows.band_rows > 0) {
+		const int band = p.lrow / rows.band_rows, within = p.lrow - band * rows.band_rows;
+		p.py = (rows.band_index + band * rows.band_count) * rows.band_rows + within;
+	} else {
+		p.py = rows.row_begin + p.lrow;
+	}
+	p.live = p.px < f.screen_w && p.lrow < rows.local_rows && p.py < f.screen_h;
+	return p;
+}
+
+// Wave-reduce and publish the per-launch counters {steps, hits, capped}.
+template <bool STATS>
+__device__ __forceinline__ void publish_counters(const StatsOut &st, unsigned long long steps,
+                                                 uint32_t hit, uint32_t cap) {
+	if (STATS) {
+		unsigned long long s = steps, h = hit, c = cap;
+		for (int off = 32; off > 0; off >>= 1) {
+			s += __shfl_xor(s, off);
+			h += __shfl_xor(h, off);
+			c += __shfl_xor(c, off);
+		}
+		if ((threadIdx.x & 63) == 0) {
+			if (s) atomicAdd(&st.counters[0], s);
+			if (h) atomicAdd(&st.counters[1], h);
+			if (c) atomicAdd(&st.counters[2], c);
+		}
+	} else if (cap) {
+		atomicAdd(&st.counters[2], 1ull);
+	}
+}
+
+} // namespace hmrm

@@ -34,12 +34,20 @@ struct DevFrame {
 	double nudge;                // grid_width * 0.01 (:998)
 	double step_dist;            // :68
 	// ---- derived, bit-preserving helpers (not in the reference) ----
-	double inv_grid_width;       // 1/grid_width, only used when grid_pow2 != 0
+	double inv_grid_width;       // fl(1/grid_width); exact iff grid_pow2 != 0
 	int32_t grid_pow2;           // grid_width is a normal power of two: x/gw == x*(1/gw) exactly
-	int32_t pad_;
+	int32_t grid_mode;           // 0: grid_width == 1.0, 1: power of two, 2: general
 	double thr_max;              // max over cells of heightmap_buf[i] + c0.z
 	int64_t step_cap;            // guard for the reference's unbounded while(true) (:1000)
+	// max pyramid over the thr table: level l holds, per (4^(l+1))^2-cell block, the
+	// maximum of thr (NaN cells ignored: z < NaN never hits).  Block edge 4, 16, 64 cells.
+	const double *mip[3];
+	int32_t mip_w[3];
+	int32_t pad2_;
 };
+
+constexpr int kMipLevels = 3;
+constexpr int kMipShift[3] = {2, 4, 6};
 
 // Which framebuffer rows a launch covers and where they land in the output.
 struct RowMap {

@@ -26,7 +26,7 @@
 
 #include <stdint.h>
 
-#include "frame.hpp"
+#include "device_common.hpp"
 #include "render.hpp"
 
 #pragma clang fp contract(off)
@@ -74,87 +74,6 @@ __global__ __launch_bounds__(256) void k_prepare_heights(const uint8_t *__restri
 		if ((threadIdx.x & 63) == 0 && local) atomicMax(max_key, local);
 	}
 }
-
-// ----------------------------------------------------------------- render ----
-struct DevRay {
-	double px, py, pz;
-	double dx, dy, dz;
-};
-
-template <int PROJ>
-__device__ __forceinline__ DevRay make_ray(const DevFrame &f, int px, int py) {
-	DevRay r;
-	if (PROJ == 2) {
-		// Spherical.cpp:23-25; sin/cos come from the host tables
-		const double sva = f.row_sin_va[py], cva = f.row_cos_va[py];
-		const double cha = f.col_cos_ha[px], sha = f.col_sin_ha[px];
-		r.px = f.cam[0]; r.py = f.cam[1]; r.pz = f.cam[2];
-		r.dx = sva * cha;
-		r.dy = sva * sha;
-		r.dz = cva;
-	} else {
-		// hmap.cpp:985-988
-		const double w = (double)px / (double)(f.screen_w - 1);
-		const double h = (double)py / (double)(f.screen_h - 1);
-		// upper_left + w*plane_right + h*plane_down  (Perspective.cpp:27, Orthographic.cpp:20)
-		const double ox = (f.upper_left[0] + w * f.plane_right[0]) + h * f.plane_down[0];
-		const double oy = (f.upper_left[1] + w * f.plane_right[1]) + h * f.plane_down[1];
-		const double oz = (f.upper_left[2] + w * f.plane_right[2]) + h * f.plane_down[2];
-		if (PROJ == 1) {
-			const double vx = ox - f.cam[0], vy = oy - f.cam[1], vz = oz - f.cam[2];
-			// glm::normalize: v * (1 / sqrt(dot(v,v))), dot = (x*x + y*y) + z*z
-			const double tx = vx * vx, ty = vy * vy, tz = vz * vz;
-			const double inv = 1.0 / __builtin_sqrt((tx + ty) + tz);
-			r.px = f.cam[0]; r.py = f.cam[1]; r.pz = f.cam[2];
-			r.dx = vx * inv;
-			r.dy = vy * inv;
-			r.dz = vz * inv;
-		} else {
-			r.px = ox; r.py = oy; r.pz = oz;
-			r.dx = f.look[0]; r.dy = f.look[1]; r.dz = f.look[2];
-		}
-	}
-	return r;
-}
-
-// AABB.cpp:49-77, axis order x,y,z, same comparisons (NaN => every test false).
-__device__ __forceinline__ double slab_distance(const DevRay &r, const DevFrame &f) {
-	const double inf = __builtin_huge_val();
-	double lo = -inf, hi = inf;
-	const double ro[3] = {r.px, r.py, r.pz};
-	const double rd[3] = {r.dx, r.dy, r.dz};
-#pragma unroll
-	for (int i = 0; i < 3; ++i) {
-		double dim_lo = (f.c0[i] - ro[i]) / rd[i];
-		double dim_hi = (f.c1[i] - ro[i]) / rd[i];
-		if (dim_lo > dim_hi) {
-			const double t = dim_lo;
-			dim_lo = dim_hi;
-			dim_hi = t;
-		}
-		if (dim_hi < lo || dim_lo > hi) return inf;
-		if (dim_lo > lo) lo = dim_lo;
-		if (dim_hi < hi) hi = dim_hi;
-	}
-	return (lo > hi) ? inf : lo;
-}
-
-__device__ __forceinline__ uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b) {
-	return r | (g << 8) | (b << 16) | 0xff000000u; // bytes R,G,B,A=255 (hmap.cpp:150-153)
-}
-
-// Clamp<double>(v,0,255) then floor then (Uint8), hmap.cpp:1049-1051
-__device__ __forceinline__ uint32_t sky_channel(double v) {
-	if (v < 0.0) v = 0.0;
-	else if (v > 255.0) v = 255.0;
-	return (uint32_t)(int)__builtin_floor(v);
-}
-
-struct StatsOut {
-	unsigned long long *counters; // [0] steps [1] hits [2] capped
-	uint32_t *steps_per_pixel;    // screen_w*screen_h or null
-	double *entry_d;              // screen_w*screen_h or null
-};
 
 template <int PROJ, bool STATS>
 __global__ __launch_bounds__(256) void k_render(const DevFrame f, const RowMap rows,

@@ -23,6 +23,16 @@ hipError_t launch_render(const DevFrame &f, const RowMap &rows, const double *d_
                          unsigned long long *d_counters, uint32_t *d_steps, double *d_entry,
                          bool stats, hipStream_t stream);
 
+// Production kernel (render_fast.hip): speculative step groups, plus exact leaps over
+// empty pyramid blocks when `leap`.  Same outputs as launch_render.
+hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr,
+                              const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
+                              unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
+                              bool leap, hipStream_t stream);
+// dst(bx,by) = max of the factor x factor block of src (NaN ignored).
+hipError_t launch_build_mip(const double *d_src, int src_w, int src_h, double *d_dst, int dst_w, int dst_h,
+                            int factor, hipStream_t stream);
+
 // GetRay + distance() of pixel (px,py): d_out7 = pos[3], dir[3], d.
 hipError_t launch_probe(const DevFrame &f, int px, int py, double *d_out7, hipStream_t stream);
 

@@ -62,7 +62,9 @@ class Camera(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("hits", C.c_uint64), ("capped", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("hits", C.c_uint64), ("capped", C.c_uint64),
+                ("leap_attempts", C.c_uint64), ("leaps", C.c_uint64), ("groups", C.c_uint64),
+                ("leaped_steps", C.c_uint64)]
 
 
 def degrees_to_rads(deg: float) -> float:

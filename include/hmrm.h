@@ -78,6 +78,11 @@ typedef struct hmrm_stats {
 	uint64_t steps;       /* height loads the reference loop executes (hmap.cpp:1013) */
 	uint64_t hits;        /* rays that end on terrain (hmap.cpp:1016)                 */
 	uint64_t capped;      /* rays stopped by the step cap (reference: endless loop)   */
+	/* traversal diagnostics of the production kernel (0 for HMRM_KERNEL=simple)      */
+	uint64_t leap_attempts; /* pyramid look-ups tried                                 */
+	uint64_t leaps;         /* ... that ended in an exact jump                        */
+	uint64_t groups;        /* speculative 4-step groups executed                     */
+	uint64_t leaped_steps;  /* ray-steps covered by jumps (part of `steps`)           */
 } hmrm_stats;
 
 typedef struct hmrm_scene hmrm_scene;    /* device-resident height + colour maps */

@@ -6,6 +6,7 @@ Sizes the oracle finishes in seconds are compared directly; BASELINE.json's
 full sizes are covered by row-subsampled oracle comparison and by
 size-independent properties (determinism, strips == full frame, counters add up).
 """
+import contextlib
 import os
 import subprocess
 
@@ -23,6 +24,24 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
+# HMRM_KERNEL: "leap" = production kernel (speculative groups + exact leaps), "group" = groups
+# only, "simple" = the literal one-step loop.  All must agree with the oracle bit for bit.
+KERNEL_VARIANTS = ("leap", "group", "simple")
+
+
+@contextlib.contextmanager
+def kernel_variant(name):
+    old = os.environ.get("HMRM_KERNEL")
+    os.environ["HMRM_KERNEL"] = name
+    try:
+        yield
+    finally:
+        if old is None:
+            del os.environ["HMRM_KERNEL"]
+        else:
+            os.environ["HMRM_KERNEL"] = old
+
+
 @pytest.fixture(scope="module")
 def gpu(hmrm):
     assert hmrm.device_count() >= 1, "no GPU visible: these tests must run on the MI355X box"
@@ -38,14 +57,18 @@ def test_frame_steps_and_distance_bit_exact(gpu, oracle, case):
     assert np.array_equal(_bits(scene.read_heights()), _bits(heights)), "UpdateHeightmap (hmap.cpp:171-191)"
     cfg = oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0])
     ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True)
-    fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
-    assert np.array_equal(_bits(entry), _bits(oentry)), "distance() (AABB.cpp:49-77)"
-    assert np.array_equal(steps.astype(np.int64), osteps), "per-ray step count (hmap.cpp:1000-1038)"
-    assert np.array_equal(fb, ofb), "frame (hmap.cpp:978-1058)"
-    assert (st.rays, st.steps, st.capped) == (cam.width * cam.height, total, 0)
-    assert st.hits <= st.rays
-    # the un-instrumented kernel writes the same pixels
-    assert np.array_equal(scene.render(cam), ofb)
+    hits = None
+    for variant in KERNEL_VARIANTS:
+        with kernel_variant(variant):
+            fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
+            assert np.array_equal(_bits(entry), _bits(oentry)), f"{variant}: distance() (AABB.cpp:49-77)"
+            assert np.array_equal(steps.astype(np.int64), osteps), f"{variant}: per-ray step count (hmap.cpp:1000-1038)"
+            assert np.array_equal(fb, ofb), f"{variant}: frame (hmap.cpp:978-1058)"
+            assert (st.rays, st.steps, st.capped) == (cam.width * cam.height, total, 0), variant
+            assert hits is None or st.hits == hits
+            hits = st.hits
+            # the un-instrumented kernel writes the same pixels
+            assert np.array_equal(scene.render(cam), ofb), variant
     scene.close()
 
 
@@ -161,6 +184,11 @@ def test_baseline_config_full_size_subsampled_and_properties(gpu, oracle, wl_nam
     fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
     fb2 = scene.render(cam)
     assert np.array_equal(fb, fb2), "instrumented and plain kernels differ"
+    for variant in ("group", "simple"):
+        with kernel_variant(variant):
+            fbv, stv, stepsv, _ = scene.render_stats(cam, per_pixel=True)
+        assert np.array_equal(fbv, fb), f"kernel variant {variant} differs from the production kernel"
+        assert np.array_equal(stepsv, steps) and stv.steps == st.steps, variant
     assert np.array_equal(scene.render(cam), fb2), "render is not deterministic"
     assert int(steps.astype(np.int64).sum()) == st.steps and st.rays == cam.width * cam.height
     assert (fb[:, :, 3] == 255).all()
