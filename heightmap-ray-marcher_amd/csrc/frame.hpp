@@ -39,15 +39,17 @@ struct DevFrame {
 	int32_t grid_mode;           // 0: grid_width == 1.0, 1: power of two, 2: general
 	double thr_max;              // max over cells of heightmap_buf[i] + c0.z
 	int64_t step_cap;            // guard for the reference's unbounded while(true) (:1000)
-	// max pyramid over the thr table: level l holds, per (4^(l+1))^2-cell block, the
-	// maximum of thr (NaN cells ignored: z < NaN never hits).  Block edge 4, 16, 64 cells.
-	const double *mip[3];
-	int32_t mip_w[3];
+	// window-maximum pyramid over the thr table (render_fast.hip): level l holds the maximum
+	// of thr (NaN ignored: z < NaN never hits) over S x S-cell windows, S = 4, 16, 64, 256,
+	// placed every S/2 cells; floats rounded up.  mip_w = windows per row.
+	const float *mip[4];
+	int32_t mip_w[4];
+	int32_t diag_mode;           // tools only: what the instrumented kernel writes per pixel
 	int32_t pad2_;
 };
 
-constexpr int kMipLevels = 3;
-constexpr int kMipShift[3] = {2, 4, 6};
+constexpr int kMipLevels = 4;
+constexpr int kMipStrideShift[4] = {1, 3, 5, 7}; // log2(S/2)
 
 // Which framebuffer rows a launch covers and where they land in the output.
 struct RowMap {

@@ -29,9 +29,11 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
                               bool leap, hipStream_t stream);
-// dst(bx,by) = max of the factor x factor block of src (NaN ignored).
-hipError_t launch_build_mip(const double *d_src, int src_w, int src_h, double *d_dst, int dst_w, int dst_h,
-                            int factor, hipStream_t stream);
+// Window-maximum pyramid (see render_fast.hip): level 0 from the thr table, level l+1 from level l.
+hipError_t launch_build_mip0(const double *d_thr, int map_w, int map_h, float *d_dst, int dst_w, int dst_h,
+                             hipStream_t stream);
+hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *d_dst, int dst_w, int dst_h,
+                               hipStream_t stream);
 
 // GetRay + distance() of pixel (px,py): d_out7 = pos[3], dir[3], d.
 hipError_t launch_probe(const DevFrame &f, int px, int py, double *d_out7, hipStream_t stream);

@@ -11,20 +11,25 @@
 //
 // (2) EXACT LEAPS.  While a coordinate p stays inside one binade [2^E, 2^(E+1)) every
 //     value is a multiple of u = 2^(E-52), and fl(p + s) = p + delta with the SAME
-//     delta = round_u(s) for every p of that binade (round-to-nearest; exact ties,
-//     where the result depends on the parity of p, are excluded).  Hence the
+//     delta = round_u(s) for every p of that binade (round-to-nearest; on an exact
+//     tie the increment is constant too once p has the steady parity: axis_refresh).  Hence the
 //     reference's sequential accumulation satisfies p_k = p_0 + k*delta EXACTLY, and
-//     both the product k*delta and the sum are exact in fp64.  A max pyramid over the
-//     hit thresholds then lets a ray jump over n steps at once when all n skipped
-//     positions provably (a) stay in the block whose maximum was looked up and
-//     (b) stay at or above that maximum (no hit possible: hmap.cpp:1016 needs
-//     z < threshold), with (c) all three coordinates inside their binades.  The jump
-//     length is only ESTIMATED (approximate reciprocals); the landing point is then
-//     VERIFIED with exact tests (cell -> block id, z >= max, exponent/sign/mantissa of
-//     each coordinate), and monotonicity of each coordinate in k extends the
-//     verification from the landing point to every skipped position.  A failed
-//     verification just means "no jump".  Skipped positions are counted as steps:
-//     each was inside the grid, so the reference executed its height load there.
+//     both the product k*delta and the sum are exact in fp64.  A pyramid of window
+//     maxima over the hit thresholds then lets a ray jump over n steps at once when
+//     all n skipped positions provably (a) stay inside the window whose maximum was
+//     looked up and (b) stay at or above that maximum (no hit possible: hmap.cpp:1016
+//     needs z < threshold), with (c) all three coordinates inside their binades.  The
+//     jump length is only ESTIMATED (approximate reciprocals); the landing point is
+//     then VERIFIED with exact tests (cell inside the window, z >= max, exponent /
+//     sign / mantissa of each coordinate), and monotonicity of each coordinate in k
+//     extends the verification from the landing point to every skipped position.  A
+//     failed verification just means "no jump".  Skipped positions are counted as
+//     steps: each was inside the grid, so the reference executed its height load there.
+//
+// Pyramid layout (built by k_build_mip*): level l holds maxima of S x S-cell windows,
+// S = 4, 16, 64, 256, placed every S/2 cells (overlapping), so that a ray can always pick
+// a window in which it has at least S/2 cells of room ahead.  Values are floats
+// rounded UP (a larger bound is always safe).  Above them: the whole map (thr_max).
 #include "device_common.hpp"
 #include "render.hpp"
 
@@ -35,7 +40,8 @@ namespace hmrm {
 namespace {
 
 constexpr int kGroup = 4;       // U: positions per speculative group
-constexpr int kMinLeap = 8;     // a jump shorter than this is not worth its bookkeeping
+constexpr int kMinLeap = 6;     // a jump shorter than this is not worth its bookkeeping
+constexpr int kTopLevel = kMipLevels; // whole-map level (thr_max, no load)
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
 __device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)(unsigned long long)__double_as_longlong(v); }
@@ -59,39 +65,49 @@ __device__ __forceinline__ double cell_coord(double v, const DevFrame &f) {
 	return q;
 }
 
-// Per-step increment of coordinate p inside p's binade.  Returns false when p + s
-// leaves the binade / changes sign, p is tiny or non-finite, or s lands on an exact
-// rounding tie (then the increment depends on the parity of p).
-__device__ __forceinline__ bool binade_delta(double p, double s, double &delta) {
-	const double p1 = p + s;
-	const uint32_t hp = hi32(p), hp1 = hi32(p1);
+// Exact-stepping state of one coordinate inside its current binade.
+struct Axis {
+	double delta;  // p_{k+1} - p_k for every p of the binade (valid iff key matches)
+	double lim;    // binade boundary the coordinate is moving towards
+	double rdel;   // ~1/delta (signed); (lim - p) * rdel estimates the steps left
+	uint32_t key;  // sign+exponent bits (hi32 >> 20) the above was measured for
+};
+
+// Measure delta at p (see file header) from TWO real steps.  Off a rounding tie the
+// increment is the same for every p of the binade.  On an exact tie (s = q*u + u/2)
+// round-to-even makes every result an even multiple of u, so from the first step on
+// the increment is constant as well (q or q+1 by the parity of q); only a start value
+// of the wrong parity steps differently once -- which shows as two unequal increments
+// and is rejected here (the next group of real steps lands on the steady parity).
+// Invalid (key = ~0) also when the two steps leave the binade or change sign, or p is
+// tiny / non-finite.
+__device__ __forceinline__ void axis_refresh(Axis &a, double p, double s) {
+	const double p1 = p + s, p2 = p1 + s;
+	const uint32_t hp = hi32(p), hp1 = hi32(p1), hp2 = hi32(p2);
 	const uint32_t e = (hp >> 20) & 0x7ffu;
-	const double d = p1 - p; // exact: both are multiples of u and |d| < 2^53 u
-	delta = d;
-	if (((hp ^ hp1) >> 20) != 0) return false; // sign or exponent changed
-	if (e < 128u || e > 1900u) return false;    // subnormal/tiny, huge, inf, NaN
-	const double err = s - d;                   // exact low part of s, |err| <= u/2
-	const double half_u = f64_from_hi((e - 53u) << 20);
-	return __builtin_fabs(err) != half_u;
+	const double d = p1 - p;                  // exact: multiples of u, |d| < 2^53 u
+	const bool ok = ((hp ^ hp1) >> 20) == 0 && ((hp ^ hp2) >> 20) == 0 && e >= 128u && e <= 1900u &&
+	                (p2 - p1) == d;
+	a.key = ok ? (hp >> 20) : 0xffffffffu;
+	a.delta = d;
+	if (d == 0.0) { // the coordinate never moves (s == 0 or absorbed): unlimited room
+		a.lim = p + 1.0;
+		a.rdel = 0x1p40;
+	} else {
+		const double lo = f64_from_hi(hp & 0x7ff00000u);          // 2^E
+		const bool away = ((hi32(d) ^ hp) >> 31) == 0;            // |p| grows
+		const double lim_abs = away ? lo + lo : lo;
+		a.lim = (hp >> 31) ? -lim_abs : lim_abs;
+		a.rdel = __builtin_amdgcn_rcp(d);
+	}
 }
 
-// p_n = p + n*delta is trustworthy iff it is still in p's binade with the same sign, and
-// -- when moving towards zero -- not exactly on the binade's lower boundary (the
-// step that produced it could have rounded on the finer grid below 2^E).
-__device__ __forceinline__ bool binade_landing_ok(double p, double pn, double delta) {
-	if (((hi32(p) ^ hi32(pn)) >> 20) != 0) return false;
-	return delta == 0.0 || (hi32(pn) & 0xfffffu) != 0u || lo32(pn) != 0u;
-}
-
-// Upper estimate of how many steps keep |p| inside its binade (not exact: verified later).
-__device__ __forceinline__ double binade_room(double p, double delta, double rcp_abs_step) {
-	if (delta == 0.0) return 0x1p40;
-	const uint32_t hp = hi32(p);
-	const double ap = __builtin_fabs(p);
-	const double lo = f64_from_hi(hp & 0x7ff00000u);
-	const bool away = ((hi32(delta) ^ hp) >> 31) == 0; // same sign: |p| grows
-	const double dist = away ? (lo + lo) - ap : ap - lo;
-	return dist * rcp_abs_step;
+// p_n = p + n*delta is trustworthy iff it is still in p's binade with the same sign,
+// and -- when the coordinate moves -- not exactly on a binade boundary (moving towards
+// zero, the step that produced it could have rounded on the finer grid below 2^E).
+__device__ __forceinline__ bool axis_landing_ok(const Axis &a, double pn) {
+	if ((hi32(pn) >> 20) != a.key) return false;
+	return a.delta == 0.0 || (hi32(pn) & 0xfffffu) != 0u || lo32(pn) != 0u;
 }
 
 } // namespace
@@ -130,84 +146,116 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 			int64_t budget = f.step_cap;
 
 			// leap state
-			int lev = kMipLevels - 1; // start coarse: rays enter the box high above the terrain
-			int cooldown = 0, penalty = 1;
-			double rsx = 0, rsy = 0, rsz = 0; // ~1/|step| in cell units (x,y) / world units (z)
-			if (LEAP) {
-				const double inv = (GWM == 0) ? 1.0 : f.inv_grid_width;
-				rsx = __builtin_amdgcn_rcp(__builtin_fabs(sx * inv));
-				rsy = __builtin_amdgcn_rcp(__builtin_fabs(sy * inv));
-				rsz = __builtin_amdgcn_rcp(__builtin_fabs(sz));
-			}
+			int lev = kTopLevel; // rays enter the box above everything: first try the whole-map bound
+			int cooldown = 0, fails = 0;
+			Axis ax, ay, az;
+			ax.key = ay.key = az.key = 0xfffffffeu; // never matches: forces the first refresh
+			ax.delta = ay.delta = az.delta = 0.0;
+			ax.lim = ay.lim = az.lim = 0.0;
+			ax.rdel = ay.rdel = az.rdel = 0.0;
+			// window choice: step back one half-window when the cell index decreases along the ray
+			const int offx = sx < 0.0 ? 1 : 0, offy = sy > 0.0 ? 1 : 0; // gy = trunc(-y/gw) falls when y grows
+			const double gwid = (GWM == 0) ? 1.0 : f.grid_width;
 
 			bool done = false;
 			while (!done) {
 				// ---------------------------------------------------------- leap
 				if (LEAP) {
-					bool tried = false, leaped = false;
+					bool leaped = false;
 					if (cooldown > 0) {
 						--cooldown;
 					} else {
-						tried = true;
 						if (STATS) ++dg_attempts;
+						if ((hi32(x) >> 20) != ax.key) axis_refresh(ax, x, sx);
+						if ((hi32(y) >> 20) != ay.key) axis_refresh(ay, y, sy);
+						if ((hi32(z) >> 20) != az.key) axis_refresh(az, z, sz);
 						const double qx = cell_coord<GWM>(x, f), qy = cell_coord<GWM>(-y, f);
-						double dx_, dy_, dz_;
-						const bool okx = binade_delta(x, sx, dx_);
-						const bool oky = binade_delta(y, sy, dy_);
-						const bool okz = binade_delta(z, sz, dz_);
-						if (qx > -1.0 && qx < wlim && qy > -1.0 && qy < hlim && okx && oky && okz) {
+						const bool inb0 = qx > -1.0 && qx < wlim && qy > -1.0 && qy < hlim;
+						const bool exact = ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
+						// outcome: 0 = leaped, 1 = too close to the window maximum (go finer),
+						//          2 = out of lateral / binade room (step a group, then retry)
+						int outcome = 2;
+						if (inb0 && exact) {
 							const int gx = (int)qx, gy = (int)qy;
-							const int sh = lev == 0 ? kMipShift[0] : (lev == 1 ? kMipShift[1] : kMipShift[2]);
-							const int bx = gx >> sh, by = gy >> sh;
-							const double *mp = lev == 0 ? f.mip[0] : (lev == 1 ? f.mip[1] : f.mip[2]);
-							const int mw = lev == 0 ? f.mip_w[0] : (lev == 1 ? f.mip_w[1] : f.mip_w[2]);
-							const double m = mp[(int64_t)by * mw + bx];
-							if (z >= m) {
-								// estimates (cell units laterally); every one is an over-estimate at
-								// worst by rounding -- the landing point is verified below
-								const double bsz = (double)(1 << sh);
-								const double bx0 = (double)(bx << sh), by0 = (double)(by << sh);
-								// x grows with sx; the y cell index grows when y decreases (qy = -y/gw)
-								double room = 0x1p30;
-								if (sx != 0.0) room = __builtin_fmin(room, (sx > 0.0 ? (bx0 + bsz) - qx : qx - bx0) * rsx);
-								if (sy != 0.0) room = __builtin_fmin(room, (sy < 0.0 ? (by0 + bsz) - qy : qy - by0) * rsy);
-								if (sz < 0.0) room = __builtin_fmin(room, (z - m) * rsz);
-								room = __builtin_fmin(room, binade_room(x, dx_, rsx * ((GWM == 0) ? 1.0 : f.inv_grid_width)));
-								room = __builtin_fmin(room, binade_room(y, dy_, rsy * ((GWM == 0) ? 1.0 : f.inv_grid_width)));
-								room = __builtin_fmin(room, binade_room(z, dz_, rsz));
+							double m;
+							int wx0, wy0, wspan_x, wspan_y;
+							if (lev == kTopLevel) {
+								m = f.thr_max;
+								wx0 = 0; wy0 = 0; wspan_x = f.map_w; wspan_y = f.map_h;
+							} else {
+								const int hs = 2 * lev + 1; // log2 of the window stride S/2
+								int ix = (gx >> hs) - offx, iy = (gy >> hs) - offy;
+								ix = ix < 0 ? 0 : ix;
+								iy = iy < 0 ? 0 : iy;
+								const float *mp = lev == 0 ? f.mip[0] : (lev == 1 ? f.mip[1] : (lev == 2 ? f.mip[2] : f.mip[3]));
+								const int mw = lev == 0 ? f.mip_w[0] : (lev == 1 ? f.mip_w[1] : (lev == 2 ? f.mip_w[2] : f.mip_w[3]));
+								m = (double)mp[iy * mw + ix];
+								wx0 = ix << hs; wy0 = iy << hs;
+								wspan_x = wspan_y = 2 << hs;
+							}
+							if (!(z >= m)) {
+								outcome = 1;
+							} else {
+								// estimates of the steps left before each constraint bites; rdel is signed
+								// like the motion, so every quotient is >= 0.  All verified below.
+								const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;      // x edge ahead
+								const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid;     // y edge ahead
+								double room = (ax.lim - x) * ax.rdel;
+								room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
+								room = __builtin_fmin(room, (az.lim - z) * az.rdel);
+								if (sx != 0.0) room = __builtin_fmin(room, (ex - x) * ax.rdel);
+								if (sy != 0.0) room = __builtin_fmin(room, (ey - y) * ay.rdel);
 								room = __builtin_fmin(room, (double)budget);
+								double room_z = 0x1p40;
+								if (sz < 0.0) room_z = (m - z) * az.rdel;
+								const bool z_bound = room_z < room;
+								room = __builtin_fmin(room, room_z);
 								const int n = (int)(room * 0.998) - 1;
+								outcome = z_bound ? 1 : 2;
 								if (n >= kMinLeap) {
 									const double nn = (double)n;
-									const double xn = x + nn * dx_, yn = y + nn * dy_, zn = z + nn * dz_;
+									const double xn = x + nn * ax.delta, yn = y + nn * ay.delta, zn = z + nn * az.delta;
 									const double qxn = cell_coord<GWM>(xn, f), qyn = cell_coord<GWM>(-yn, f);
 									bool ok = qxn > -1.0 && qxn < wlim && qyn > -1.0 && qyn < hlim;
-									ok = ok && (((int)qxn) >> sh) == bx && (((int)qyn) >> sh) == by;
+									ok = ok && (unsigned)((int)qxn - wx0) < (unsigned)wspan_x &&
+									     (unsigned)((int)qyn - wy0) < (unsigned)wspan_y;
 									ok = ok && zn >= m;
-									ok = ok && binade_landing_ok(x, xn, dx_) && binade_landing_ok(y, yn, dy_) &&
-									     binade_landing_ok(z, zn, dz_);
+									ok = ok && axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
 									if (ok) {
 										x = xn; y = yn; z = zn;
 										budget -= n;
 										if (STATS) { my_steps += (unsigned)n; dg_leaped += (unsigned)n; ++dg_leaps; }
 										leaped = true;
+										outcome = z_bound ? 1 : 0;
 									}
 								}
 							}
 						}
-					}
-					if (tried) {
-						if (leaped) {
-							penalty = 1;
+						// level policy (performance only; any policy gives the same pixels):
+						//   window crossed (0)      -> coarser next time
+						//   height bound hit (1)    -> finer; without a jump retry at once (no progress is
+						//                              lost, the level strictly decreases); at the finest
+						//                              level march two groups before looking again
+						//   no lateral/binade room  -> coarser (a bigger window has more room), and march
+						//   or not exact (2)           with a growing pause while attempts keep failing
+						bool retry = false;
+						if (outcome == 0) {
+							fails = 0;
 							if (lev < kMipLevels - 1) ++lev;
-						} else if (lev > 0) {
-							--lev;
+						} else if (outcome == 1) {
+							if (leaped) fails = 0;
+							if (lev == kTopLevel) lev = kMipLevels - 1;
+							else if (lev > 0) { --lev; retry = !leaped; }
+							else if (!leaped) cooldown = 1;
 						} else {
-							cooldown = penalty;
-							if (penalty < 8) penalty <<= 1;
+							if (lev == kTopLevel) lev = kMipLevels - 1;
+							else if (lev < kMipLevels - 1) ++lev;
+							cooldown = fails < 3 ? fails : 3;
+							++fails;
 						}
+						if (retry) continue;
 					}
-					if (leaped) continue; // try the next block straight away
+					if (leaped) continue; // try the next window straight away
 				}
 
 				// --------------------------------------------- speculative group
@@ -234,7 +282,6 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 				for (int j = 0; j < kGroup; ++j) T[j] = thr[cell[j]]; // hmap.cpp:1013-1014 (+ c0.z)
 #pragma unroll
 				for (int j = 0; j < kGroup; ++j) {
-					if (done) break;
 					if (!inb[j]) { done = true; break; }
 					if (budget <= 0) { my_cap = 1; done = true; break; }
 					--budget;
@@ -259,7 +306,9 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 		out[(int64_t)pid.lrow * out_stride_px + pid.px] = rgba;
 		if (STATS && st.steps_per_pixel)
 			st.steps_per_pixel[(int64_t)pid.py * f.screen_w + pid.px] =
-			    my_steps > 0xffffffffull ? 0xffffffffu : (uint32_t)my_steps;
+			    f.diag_mode == 1 ? ((dg_attempts > 0xffffu ? 0xffffu : dg_attempts) << 16) |
+			                       (dg_groups > 0xffffu ? 0xffffu : dg_groups)
+			                 : (my_steps > 0xffffffffull ? 0xffffffffu : (uint32_t)my_steps);
 	}
 	publish_counters<STATS>(st, my_steps, my_hit, my_cap);
 	if (STATS) {
@@ -279,29 +328,72 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 	}
 }
 
-// Max pyramid: dst(bx,by) = max over the factor x factor block of src (NaN ignored).
-__global__ __launch_bounds__(256) void k_build_mip(const double *__restrict__ src, int src_w, int src_h,
-                                                   double *__restrict__ dst, int dst_w, int dst_h, int factor) {
+// ---------------------------------------------------------------- pyramid ----
+__device__ __forceinline__ float round_up_to_float(double v) {
+	float r = (float)v;
+	if ((double)r < v) { // conversion rounded down (v finite): next float towards +inf
+		uint32_t b = __float_as_uint(r);
+		if (r == 0.0f) b = 1u;                 // smallest positive subnormal
+		else if (b & 0x80000000u) b -= 1u;     // negative: magnitude shrinks
+		else b += 1u;                          // positive: magnitude grows (max float -> +inf)
+		r = __uint_as_float(b);
+	}
+	return r;
+}
+
+// Level 0: window (ix,iy) = max of thr over cells [2ix, 2ix+4) x [2iy, 2iy+4), clipped; NaN ignored.
+__global__ __launch_bounds__(256) void k_build_mip0(const double *__restrict__ thr, int map_w, int map_h,
+                                                    float *__restrict__ dst, int dst_w, int dst_h) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (int64_t)dst_w * dst_h) return;
-	const int bx = (int)(i % dst_w), by = (int)(i / dst_w);
+	const int ix = (int)(i % dst_w), iy = (int)(i / dst_w);
 	double m = -__builtin_huge_val();
-	for (int yy = by * factor; yy < (by + 1) * factor && yy < src_h; ++yy)
-		for (int xx = bx * factor; xx < (bx + 1) * factor && xx < src_w; ++xx) {
-			const double v = src[(int64_t)yy * src_w + xx];
+	for (int yy = 2 * iy; yy < 2 * iy + 4 && yy < map_h; ++yy)
+		for (int xx = 2 * ix; xx < 2 * ix + 4 && xx < map_w; ++xx) {
+			const double v = thr[(int64_t)yy * map_w + xx];
 			if (v > m) m = v;
 		}
+	dst[i] = round_up_to_float(m);
+}
+
+// Level l+1 from level l: a window of 4S cells at cell 8H*i (H = stride of level l) is the union of
+// the level-l windows with indices 4i + {0,2,4,6} (each S cells wide, starting every 2H cells).
+__global__ __launch_bounds__(256) void k_build_mip_up(const float *__restrict__ src, int src_w, int src_h,
+                                                      float *__restrict__ dst, int dst_w, int dst_h) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (int64_t)dst_w * dst_h) return;
+	const int ix = (int)(i % dst_w), iy = (int)(i / dst_w);
+	float m = -__builtin_huge_valf();
+	for (int b = 0; b < 4; ++b) {
+		const int yy = 4 * iy + 2 * b;
+		if (yy >= src_h) break;
+		for (int a = 0; a < 4; ++a) {
+			const int xx = 4 * ix + 2 * a;
+			if (xx >= src_w) break;
+			const float v = src[(int64_t)yy * src_w + xx];
+			if (v > m) m = v;
+		}
+	}
 	dst[i] = m;
 }
 
-hipError_t launch_build_mip(const double *d_src, int src_w, int src_h, double *d_dst, int dst_w, int dst_h,
-                            int factor, hipStream_t stream) {
+hipError_t launch_build_mip0(const double *d_thr, int map_w, int map_h, float *d_dst, int dst_w, int dst_h,
+                             hipStream_t stream) {
 	const int64_t n = (int64_t)dst_w * dst_h;
-	hipLaunchKernelGGL(k_build_mip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_src, src_w,
-	                   src_h, d_dst, dst_w, dst_h, factor);
+	hipLaunchKernelGGL(k_build_mip0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_thr, map_w,
+	                   map_h, d_dst, dst_w, dst_h);
 	return hipGetLastError();
 }
 
+hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *d_dst, int dst_w, int dst_h,
+                               hipStream_t stream) {
+	const int64_t n = (int64_t)dst_w * dst_h;
+	hipLaunchKernelGGL(k_build_mip_up, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_src, src_w,
+	                   src_h, d_dst, dst_w, dst_h);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- launch ----
 template <int PROJ, bool STATS, int GWM, bool LEAP>
 static void launch_one(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
                        uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid, int tiles_x,
