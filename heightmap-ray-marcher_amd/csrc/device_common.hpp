@@ -77,6 +77,32 @@ __device__ __forceinline__ double slab_distance(const DevRay &r, const DevFrame 
 	return (lo > hi) ? inf : lo;
 }
 
+// Cheap proof that slab_distance() would report a miss (inf, or an entry distance < 0:
+// AABB.cpp:33-40), from approximate reciprocals.  Each approximate slab parameter t'
+// has the sign of the exact quotient and a relative error far below 2^-16, so:
+//   (A) min_i hi'_i < 0          => the exact hi is negative => d <= hi < 0 or d = inf;
+//   (B) max_i lo'_i exceeds min_i hi'_i by more than the error bars => the exact intervals
+//       do not overlap => distance() returns inf (early or at its last line).
+// Either way the pixel is a miss; nothing else about d is used for a miss.  Returns false
+// ("don't know", take the exact path) whenever a direction component is zero or anything
+// is non-finite.
+__device__ __forceinline__ bool slab_surely_misses(const DevRay &r, const DevFrame &f) {
+	const double ro[3] = {r.px, r.py, r.pz};
+	const double rd[3] = {r.dx, r.dy, r.dz};
+	double LO = -__builtin_huge_val(), HI = __builtin_huge_val(), mag = 0.0;
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		if (!(__builtin_fabs(rd[i]) > 0x1p-500) || !(__builtin_fabs(rd[i]) < 0x1p500)) return false;
+		const double inv = __builtin_amdgcn_rcp(rd[i]);
+		const double t0 = (f.c0[i] - ro[i]) * inv, t1 = (f.c1[i] - ro[i]) * inv;
+		if (!(__builtin_fabs(t0) < 0x1p500) || !(__builtin_fabs(t1) < 0x1p500)) return false;
+		LO = __builtin_fmax(LO, __builtin_fmin(t0, t1));
+		HI = __builtin_fmin(HI, __builtin_fmax(t0, t1));
+		mag = __builtin_fmax(mag, __builtin_fmax(__builtin_fabs(t0), __builtin_fabs(t1)));
+	}
+	return HI < 0.0 || (LO - HI) > mag * 0x1p-12;
+}
+
 __device__ __forceinline__ uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b) {
 	return r | (g << 8) | (b << 16) | 0xff000000u; // bytes R,G,B,A=255 (hmap.cpp:150-153)
 }
