@@ -28,6 +28,15 @@ int fail(int code, const std::string &msg) {
 	return code;
 }
 
+} // namespace
+
+namespace hmrm {
+// for the other translation units of the library (record.cpp)
+int set_error(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+} // namespace hmrm
+
+namespace {
+
 #define HIP_TRY(expr)                                                                         \
 	do {                                                                                      \
 		hipError_t e_ = (expr);                                                               \
@@ -560,6 +569,7 @@ int32_t hmrm_config_recording_frame_count(const hmrm_config *c) { return c->cfg.
 const char *hmrm_config_heightmap_path(const hmrm_config *c) { return c->cfg.heightmap_path.c_str(); }
 const char *hmrm_config_colormap_path(const hmrm_config *c) { return c->cfg.colormap_path.c_str(); }
 const char *hmrm_config_output_path(const hmrm_config *c) { return c->cfg.output_path.c_str(); }
+int32_t hmrm_config_record_mode(const hmrm_config *c) { return c->cfg.record_mode; }
 
 const uint8_t *hmrm_config_height_rgb(const hmrm_config *c, int32_t *w, int32_t *h) {
 	if (!c->cfg.have_heightmap) return nullptr;

@@ -189,6 +189,13 @@ bool Config::consume(std::istream &input, std::string *fatal) {
 		} else if (next == "output") { // additive
 			input >> output_path;
 			log << "output " << output_path << "\n";
+		} else if (next == "record") { // additive: programmatic animation (hmap.cpp:907-926 is a stub)
+			std::string v;
+			input >> v;
+			if (v == "orbit") record_mode = 1;
+			else if (v == "off") record_mode = 0;
+			else warn << "WARNING: Unknown record mode: " << v << "\n";
+			log << "record " << (record_mode == 1 ? "orbit" : "off") << "\n";
 		} else {
 			warn << "WARNING: Unknown identifier: " << next << "\n";
 		}

@@ -32,6 +32,8 @@ struct Config {
 	uint8_t bg_r = 0, bg_g = 0, bg_b = 0;
 	// additive (north_star): output file; empty = caller decides
 	std::string output_path;
+	// additive: `record orbit` renders recording_frame_count frames of an orbit sweep
+	int record_mode = 0;
 
 	bool heightmap_dirty = false; // should_update_heightmap, sticky until taken
 	std::ostringstream log;       // what the reference prints to stdout

@@ -9,6 +9,7 @@
 // given (.ppm selects binary PPM), else screenshots/hmap_<epoch>.png.
 #include <sys/stat.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +46,34 @@ int main(int argc, char *argv[]) {
 	if (hmrm_config_create_scene(cfg, &scene) != HMRM_OK) {
 		std::cerr << hmrm_last_error() << "\n";
 		return 1;
+	}
+
+	if (hmrm_config_record_mode(cfg) == 1) {
+		// `record orbit`: recording_frame_count frames on a circle around the map centre through
+		// the configured camera position, always looking at the centre;
+		// files screenshots/hmap_<epoch>_<n>.png as hmap.cpp:1131-1144.
+		hmrm_scene_params sp;
+		hmrm_config_get_scene_params(cfg, &sp);
+		int32_t mw = 0, mh = 0;
+		hmrm_config_height_rgb(cfg, &mw, &mh);
+		const double cx = mw * sp.grid_width / 2.0, cy = -(mh * sp.grid_width) / 2.0;
+		const double dx = cx - cam.pos[0], dy = cy - cam.pos[1];
+		const double radius = std::sqrt(dx * dx + dy * dy);
+		const double hang0 = std::atan2(dy, dx);
+		std::time_t id = std::time(NULL);
+		if (id == (std::time_t)(-1)) {
+			std::cerr << "Failed to get time for recording. Recording NOT started.\n"; // hmap.cpp:886-892
+			return 1;
+		}
+		std::string dir = hmrm_config_output_path(cfg);
+		if (dir.empty()) dir = "screenshots";
+		mkdir(dir.c_str(), 0777);
+		rc = hmrm_record_orbit(scene, &cam, cx, cy, radius, hang0, hmrm_config_recording_frame_count(cfg),
+		                       dir.c_str(), (long long)id, 0, 1);
+		if (rc != HMRM_OK) std::cerr << hmrm_last_error() << "\n";
+		hmrm_scene_destroy(scene);
+		hmrm_config_destroy(cfg);
+		return rc == HMRM_OK ? 0 : 1;
 	}
 
 	std::vector<uint8_t> framebuf((size_t)cam.width * cam.height * 4);

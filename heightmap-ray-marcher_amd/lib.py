@@ -106,6 +106,11 @@ def _load():
         "hmrm_debug_frame": (C.c_int, [C.POINTER(Camera), C.POINTER(SceneParams), i32, i32, vp, vp]),
         "hmrm_last_kernel_ms": (C.c_double, []),
         "hmrm_bench_kernel_ms": (C.c_double, [vp, C.POINTER(Camera), i32]),
+        "hmrm_orbit_camera": (None, [C.POINTER(Camera), C.c_double, C.c_double, C.c_double, C.c_double, i32, i32,
+                                     C.POINTER(Camera)]),
+        "hmrm_record_orbit": (C.c_int, [vp, C.POINTER(Camera), C.c_double, C.c_double, C.c_double, C.c_double, i32,
+                                        C.c_char_p, C.c_longlong, i32, i32]),
+        "hmrm_config_record_mode": (i32, [vp]),
         "hmrm_config_create": (vp, []),
         "hmrm_config_destroy": (None, [vp]),
         "hmrm_config_consume_file": (C.c_int, [vp, C.c_char_p]),
@@ -255,6 +260,21 @@ def debug_frame(cam: Camera, params: SceneParams, map_w: int, map_h: int):
     return rec
 
 
+def orbit_camera(base: Camera, centre_x: float, centre_y: float, radius: float, hang0: float,
+                 frame: int, frames: int) -> Camera:
+    """Frame `frame` of an orbit sweep (BASELINE config C5); see hmrm_orbit_camera."""
+    out = Camera()
+    lib.hmrm_orbit_camera(C.byref(base), centre_x, centre_y, radius, hang0, frame, frames, C.byref(out))
+    return out
+
+
+def record_orbit(scene: "Scene", base: Camera, centre_x, centre_y, radius, hang0, frames, directory, rec_id,
+                 encoder_threads=0, verbose=False):
+    _check(lib.hmrm_record_orbit(scene._h, C.byref(base), centre_x, centre_y, radius, hang0, frames,
+                                 os.fsencode(directory), rec_id, encoder_threads, int(verbose)),
+           allow=(HMRM_E_NOTERM,))
+
+
 def band_local_rows(height, band_rows, band_index, band_count) -> int:
     return int(lib.hmrm_band_local_rows(height, band_rows, band_index, band_count))
 
@@ -313,6 +333,10 @@ class Config:
     @property
     def colormap_path(self) -> str:
         return lib.hmrm_config_colormap_path(self._h).decode()
+
+    @property
+    def record_mode(self) -> int:
+        return lib.hmrm_config_record_mode(self._h)
 
     @property
     def output_path(self) -> str:

@@ -33,25 +33,32 @@ def _hash2(ix: np.ndarray, iy: np.ndarray, seed: int) -> np.ndarray:
 def value_noise_u8(size: int, seed: int = SEED, octaves: int = 6) -> np.ndarray:
     """size x size uint8: `octaves` octaves of bilinearly interpolated lattice noise,
     lattice spacing size/4, size/8, ...; amplitude halves per octave. Integer only."""
-    ys, xs = np.meshgrid(np.arange(size, dtype=np.int64), np.arange(size, dtype=np.int64), indexing="ij")
-    acc = np.zeros((size, size), dtype=np.int64)
-    total = 0
-    for o in range(octaves):
-        spacing = max(size >> (o + 2), 1)
-        cx, cy = xs // spacing, ys // spacing
-        fx = ((xs % spacing) * 256) // spacing  # 0..255
-        fy = ((ys % spacing) * 256) // spacing
-        s = (seed + 0x632BE5AB * o) & 0xFFFFFFFF
-        v00 = (_hash2(cx, cy, s) >> np.uint32(16)).astype(np.int64)
-        v10 = (_hash2(cx + 1, cy, s) >> np.uint32(16)).astype(np.int64)
-        v01 = (_hash2(cx, cy + 1, s) >> np.uint32(16)).astype(np.int64)
-        v11 = (_hash2(cx + 1, cy + 1, s) >> np.uint32(16)).astype(np.int64)
-        top = v00 * (256 - fx) + v10 * fx
-        bot = v01 * (256 - fx) + v11 * fx
-        val = (top * (256 - fy) + bot * fy) >> 16  # 0..65535
-        acc += val >> o
-        total += 65535 >> o
-    return ((acc * 255) // total).astype(np.uint8)
+    out = np.empty((size, size), dtype=np.uint8)
+    total = sum(65535 >> o for o in range(octaves))
+    rows_per_block = max(1, min(size, (1 << 22) // size))  # bounded temporaries (~4 M pixels per block)
+    xs_row = np.arange(size, dtype=np.int64)[None, :]
+    for r0 in range(0, size, rows_per_block):
+        r1 = min(size, r0 + rows_per_block)
+        ys = np.arange(r0, r1, dtype=np.int64)[:, None]
+        xs = np.broadcast_to(xs_row, (r1 - r0, size))
+        ys = np.broadcast_to(ys, (r1 - r0, size))
+        acc = np.zeros((r1 - r0, size), dtype=np.int64)
+        for o in range(octaves):
+            spacing = max(size >> (o + 2), 1)
+            cx, cy = xs // spacing, ys // spacing
+            fx = ((xs % spacing) * 256) // spacing  # 0..255
+            fy = ((ys % spacing) * 256) // spacing
+            s = (seed + 0x632BE5AB * o) & 0xFFFFFFFF
+            v00 = (_hash2(cx, cy, s) >> np.uint32(16)).astype(np.int64)
+            v10 = (_hash2(cx + 1, cy, s) >> np.uint32(16)).astype(np.int64)
+            v01 = (_hash2(cx, cy + 1, s) >> np.uint32(16)).astype(np.int64)
+            v11 = (_hash2(cx + 1, cy + 1, s) >> np.uint32(16)).astype(np.int64)
+            top = v00 * (256 - fx) + v10 * fx
+            bot = v01 * (256 - fx) + v11 * fx
+            val = (top * (256 - fy) + bot * fy) >> 16  # 0..65535
+            acc += val >> o
+        out[r0:r1] = ((acc * 255) // total).astype(np.uint8)
+    return out
 
 
 def synth_maps(size: int, seed: int = SEED):
@@ -59,9 +66,10 @@ def synth_maps(size: int, seed: int = SEED):
     height-ramp colour map textured by a second hash; alpha 255 everywhere."""
     v = value_noise_u8(size, seed)
     height_rgb = np.repeat(v[:, :, None], 3, axis=2)
-    ys, xs = np.meshgrid(np.arange(size, dtype=np.int64), np.arange(size, dtype=np.int64), indexing="ij")
+    xs = np.arange(size, dtype=np.int64)[None, :]
+    ys = np.arange(size, dtype=np.int64)[:, None]
     tex = (_hash2(xs, ys, seed ^ 0x5BD1E995) & np.uint32(0x1F)).astype(np.uint8)
-    vi = v.astype(np.int64)
+    vi = v.astype(np.int32)
     r = np.clip(vi * 2 - 96, 0, 255).astype(np.uint8) ^ tex
     g = np.clip(64 + (vi * 3) // 4, 0, 255).astype(np.uint8) ^ tex
     b = np.clip(160 - vi, 0, 255).astype(np.uint8) ^ tex
@@ -97,18 +105,14 @@ class Workload:
         frames > 1 the camera orbits the map centre at radius 0.9*S (config C5);
         frame 0 of the orbit is the static pose up to rounding of R."""
         s = float(self.map_size)
-        if frames > 1:
-            hang_deg = -45.0 + 360.0 * frame / frames
-            hang = _lib.degrees_to_rads(hang_deg)
-            radius = 0.9 * s
-            pos = (s / 2.0 - radius * float(np.cos(hang)), -s / 2.0 - radius * float(np.sin(hang)), s / 4.0)
-        else:
-            hang = _lib.degrees_to_rads(-45.0)
-            pos = (-s / 8.0, s / 8.0, s / 4.0)
-        return _lib.Camera.make(width=self.width, height=self.height, projection=self.projection,
-                                hfov=_lib.degrees_to_rads(self.hfov_deg), hang=hang,
-                                vang=_lib.degrees_to_rads(115.0), pos=pos,
+        base = _lib.Camera.make(width=self.width, height=self.height, projection=self.projection,
+                                hfov=_lib.degrees_to_rads(self.hfov_deg), hang=_lib.degrees_to_rads(-45.0),
+                                vang=_lib.degrees_to_rads(115.0), pos=(-s / 8.0, s / 8.0, s / 4.0),
                                 ortho_width=self.ortho_width, step_dist=self.step_dist, bg=(0, 0, 0))
+        if frames > 1:
+            # one definition of the sweep: the library's (hmrm_orbit_camera)
+            return _lib.orbit_camera(base, s / 2.0, -s / 2.0, 0.9 * s, _lib.degrees_to_rads(-45.0), frame, frames)
+        return base
 
 
 # BASELINE.json configs[0..4], made concrete as in BASELINE.md.

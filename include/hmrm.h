@@ -165,13 +165,29 @@ double hmrm_last_kernel_ms(void);
  * events on the launch stream; <0 on error.  Bench hook. */
 double hmrm_bench_kernel_ms(const hmrm_scene *scene, const hmrm_camera *cam, int32_t iters);
 
+/* ---------------------------------------------------------------- recording */
+/* Programmatic animation for the reference's recording mode (hmap.cpp:869-900,
+ * :916-926 is an empty "alter this block and recompile" stub, :1131-1144 saves
+ * frames).  The sweep is the orbit of BASELINE config C5: camera of frame k of
+ * `frames` on a horizontal circle of `radius` around (centre_x, centre_y), looking at
+ * the centre: hang_k = hang0 + 2*pi*k/frames, pos_k = centre - radius*(cos, sin)(hang_k);
+ * everything else from `base`. */
+void hmrm_orbit_camera(const hmrm_camera *base, double centre_x, double centre_y, double radius,
+                       double hang0, int32_t frame, int32_t frames, hmrm_camera *out);
+/* Renders `frames` orbit frames and saves them as <dir>/hmap_<id>_<n>.png
+ * (hmap.cpp:1132-1134) with a pool of PNG encoder threads (0 = one per host core).
+ * verbose != 0 prints the reference's "Saved screenshot at ..." / "Done recording." lines. */
+int hmrm_record_orbit(const hmrm_scene *scene, const hmrm_camera *base, double centre_x, double centre_y,
+                      double radius, double hang0, int32_t frames, const char *dir, long long id,
+                      int32_t encoder_threads, int32_t verbose);
+
 /* ------------------------------------------------------------------- config */
 /* Replaces ConsumeConfigStream (main/hmap.cpp:309-520) and the globals'
  * defaults (:31-112).  Same whitespace token grammar, same 27 keys, same echo of
  * every option to `echo_fd`-style sinks: echo text is appended to an internal
  * log retrievable with hmrm_config_log().  Additive keys (not in the reference,
  * named by north_star): `projection perspective|spherical|orthographic|1|2|3`,
- * `output <path.png|.ppm>`.  Unknown key -> "WARNING: Unknown identifier: k". */
+ * `output <path.png|.ppm>`, `record orbit|off`.  Unknown key -> "WARNING: Unknown identifier: k". */
 hmrm_config *hmrm_config_create(void);
 void         hmrm_config_destroy(hmrm_config *cfg);
 /* Consume a whole stream; loads heightmap/colormap images when those keys
@@ -187,6 +203,7 @@ int32_t      hmrm_config_recording_frame_count(const hmrm_config *cfg);
 const char  *hmrm_config_heightmap_path(const hmrm_config *cfg);
 const char  *hmrm_config_colormap_path(const hmrm_config *cfg);
 const char  *hmrm_config_output_path(const hmrm_config *cfg);
+int32_t      hmrm_config_record_mode(const hmrm_config *cfg);   /* additive `record orbit|off`: 1|0 */
 /* Loaded maps (owned by cfg): RGB8 / RGBA8; NULL until the key was consumed. */
 const uint8_t *hmrm_config_height_rgb(const hmrm_config *cfg, int32_t *w, int32_t *h);
 const uint8_t *hmrm_config_color_rgba(const hmrm_config *cfg, int32_t *w, int32_t *h);

@@ -145,3 +145,26 @@ def test_cli_usage_and_errors(hmrm, tmp_path):
     cfg.write_text("resolution 4 4\n")
     r = subprocess.run([exe, str(cfg)], capture_output=True, text=True)
     assert r.returncode == 1 and r.stdout == "resolution 4 4\n" and r.stderr == "Must specify heightmap in config\n"
+
+
+def test_record_key_and_orbit_camera(hmrm, maps):
+    """Additive `record orbit` key + the orbit sweep of BASELINE config C5 (hmrm_orbit_camera)."""
+    hp, cp, *_ = maps
+    cfg = hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} record orbit recording_frame_count 64")
+    assert cfg.record_mode == 1 and cfg.recording_frame_count == 64 and "record orbit" in cfg.log
+    assert hmrm.Config().consume_string(f"heightmap {hp} colormap {cp}").record_mode == 0
+    wl = hmrm.synth.WORKLOADS["C5"]
+    s = float(wl.map_size)
+    static = wl.camera()
+    for k in (0, 1, 16, 63):
+        cam = wl.camera(k, 64)
+        # on the circle of radius 0.9*S around the map centre (S/2, -S/2), same height
+        dx, dy = cam.pos[0] - s / 2.0, cam.pos[1] + s / 2.0
+        assert abs(math.hypot(dx, dy) - 0.9 * s) < 1e-9 * s and cam.pos[2] == static.pos[2]
+        # looking at the centre: (cos hang, sin hang) points from the camera to the centre
+        assert abs(math.cos(cam.hang) * 0.9 * s + dx) < 1e-9 * s and abs(math.sin(cam.hang) * 0.9 * s + dy) < 1e-9 * s
+        assert cam.hang == hmrm.degrees_to_rads(-45.0) + (2.0 * math.pi * k) / 64.0
+        assert (cam.width, cam.height, cam.vang, cam.step_dist) == (static.width, static.height, static.vang, static.step_dist)
+    # frame 0 is the static pose up to the rounding of 0.9*S*cos(45 deg) vs S/8 + S/2
+    c0 = wl.camera(0, 64)
+    assert abs(c0.pos[0] - static.pos[0]) < 0.02 * s and abs(c0.pos[1] - static.pos[1]) < 0.02 * s

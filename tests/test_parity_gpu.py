@@ -253,3 +253,57 @@ def test_cli_end_to_end(gpu, oracle, tmp_path):
         assert np.array_equal(img, ofb)
         if ext == "png":
             assert open(outp, "rb").read() == gpu.png_encode(ofb)
+
+
+def test_recording_orbit_writes_reference_named_pngs(gpu, oracle, tmp_path):
+    """`record orbit`: frames <dir>/hmap_<id>_<n>.png (hmap.cpp:1132-1134), each equal to the oracle's frame."""
+    rgb, cmap = scenes.small_maps(64, 64, 41)
+    params = gpu.SceneParams.make(0.0, 8.0, grid_width=1.0)
+    base = gpu.Camera.make(width=80, height=45, projection=1, hfov=gpu.degrees_to_rads(80), hang=0.0,
+                           vang=gpu.degrees_to_rads(112), pos=(-20.0, 20.0, 30.0), step_dist=0.5, bg=(4, 5, 6))
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    frames, cx, cy, radius, hang0 = 5, 32.0, -32.0, 70.0, gpu.degrees_to_rads(-45.0)
+    out = tmp_path / "rec"
+    out.mkdir()
+    gpu.record_orbit(scene, base, cx, cy, radius, hang0, frames, str(out), 1234, encoder_threads=3)
+    assert sorted(p.name for p in out.iterdir()) == [f"hmap_1234_{k}.png" for k in range(frames)]
+    for k in range(frames):
+        cam = gpu.orbit_camera(base, cx, cy, radius, hang0, k, frames)
+        ofb, *_ = oracle.render(oracle.make_cfg(cam, params, 64, 64), heights, cmap)
+        img, n = gpu.image_load(str(out / f"hmap_1234_{k}.png"), 4)
+        assert n == 4 and np.array_equal(img, ofb), k
+        assert (out / f"hmap_1234_{k}.png").read_bytes() == gpu.png_encode(ofb)
+    scene.close()
+    # CLI: `record orbit` + recording_frame_count
+    hp, cp = str(tmp_path / "h.ppm"), str(tmp_path / "c.png")
+    gpu.write_ppm(hp, rgb)
+    gpu.write_png(cp, cmap)
+    cfgp = tmp_path / "rec.txt"
+    cfgp.write_text(f"resolution 40 30 pos -20 20 30 vang 112 max_height 8 grid_width 1 step_dist 0.5 cycle 1\n"
+                    f"heightmap {hp}\ncolormap {cp}\nrecord orbit recording_frame_count 3 output {tmp_path / 'cli'}\n")
+    exe = os.path.join(os.path.dirname(gpu.LIB_PATH), "hmap")
+    r = subprocess.run([exe, str(cfgp)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.rstrip().endswith("Done recording.") and r.stdout.count("Saved screenshot at ") == 3
+    assert len(list((tmp_path / "cli").iterdir())) == 3
+
+
+def test_c4_orthographic_8192_subsampled(gpu, oracle):
+    """BASELINE config C4 on one GPU: 7680x4320 orthographic over an 8192^2 map (every 96th row vs oracle)."""
+    wl = gpu.synth.WORKLOADS["C4"]
+    rgb, cmap = gpu.synth.synth_maps(wl.map_size)
+    params, cam = wl.scene_params(), wl.camera()
+    scene = gpu.Scene(rgb, cmap, params)
+    fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
+    assert np.array_equal(scene.render(cam), fb)
+    assert int(steps.astype(np.int64).sum()) == st.steps and st.capped == 0
+    heights = oracle.update_heightmap(rgb, params)
+    stride = 96
+    ofb, total, capped, osteps, oentry = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size),
+                                                       heights, cmap, per_pixel=True, row_stride=stride)
+    rows = slice(0, cam.height, stride)
+    assert capped == 0 and np.array_equal(fb[rows], ofb[rows])
+    assert np.array_equal(steps[rows].astype(np.int64), osteps[rows])
+    assert np.array_equal(_bits(entry[rows]), _bits(oentry[rows]))
+    scene.close()
