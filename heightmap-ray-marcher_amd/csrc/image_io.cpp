@@ -576,10 +576,8 @@ bool decode_image(const uint8_t *bytes, size_t len, int req_comp, Image *out, st
 	if (len >= 8 && memcmp(bytes, sig, 8) == 0) return decode_png(bytes, len, req_comp, out, err);
 	if (len >= 2 && bytes[0] == 'P' && (bytes[1] == '5' || bytes[1] == '6'))
 		return decode_pnm(bytes, len, req_comp, out, err);
-	if (len >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8)
-		*err = "JPEG is not decoded natively yet (supported: PNG, binary PGM/PPM)";
-	else
-		*err = "unknown image type (supported: PNG, binary PGM/PPM)";
+	if (len >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8) return decode_jpeg(bytes, len, req_comp, out, err);
+	*err = "unknown image type (supported: PNG, JPEG, binary PGM/PPM)";
 	return false;
 }
 

@@ -15,11 +15,13 @@ struct Image {
 	std::vector<uint8_t> px;  // row-major, top-left origin, 8 bits per channel
 };
 
-// Decode PNG or binary PNM from memory into 8-bit channels, converted to
+// Decode PNG, JPEG or binary PNM from memory into 8-bit channels, converted to
 // req_comp (0 = keep) the way stb_image v2.27's stbi_load does.  On failure
 // returns false and sets err to a short reason.
 bool decode_image(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
 bool load_image_file(const char *path, int req_comp, Image *out, std::string *err);
+// Baseline / progressive JPEG (jpeg_decode.cpp), same conventions.
+bool decode_jpeg(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
 
 // PNG encoder producing the same bytes as stb_image_write v1.16's
 // stbi_write_png_to_mem at its defaults (compression level 8, filter chosen per

@@ -204,6 +204,64 @@ def make_png_encode(ref):
     print("png_encode.json:", len(out), "images")
 
 
+def jpeg_fixture_files():
+    """Small JPEGs written with Pillow (only needed when regenerating): baseline and
+    progressive, 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, CMYK (Adobe APP14), RGB without
+    colour transform, restart intervals, optimised Huffman tables, odd sizes."""
+    import io
+    from PIL import Image
+    rng = np.random.RandomState(4321)
+
+    def picture(h, w, c):
+        base = rng.randint(0, 256, size=(h // 8 + 2, w // 8 + 2, c)).astype(np.float64)
+        ys, xs = np.arange(h) / 8.0, np.arange(w) / 8.0
+        y0, x0 = ys.astype(int), xs.astype(int)
+        fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+        v = (base[np.ix_(y0, x0)] * (1 - fy) * (1 - fx) + base[np.ix_(y0 + 1, x0)] * fy * (1 - fx)
+             + base[np.ix_(y0, x0 + 1)] * (1 - fy) * fx + base[np.ix_(y0 + 1, x0 + 1)] * fy * fx)
+        return np.clip(v + rng.randint(-24, 25, size=v.shape), 0, 255).astype(np.uint8)
+
+    def save(arr, mode, **kw):
+        buf = io.BytesIO()
+        Image.fromarray(arr if arr.shape[2] > 1 else arr[:, :, 0], mode).save(buf, "JPEG", **kw)
+        return buf.getvalue()
+
+    files = {}
+    rgb = picture(37, 29, 3)
+    files["rgb_444_q90"] = save(rgb, "RGB", quality=90, subsampling=0)
+    files["rgb_422_q75"] = save(rgb, "RGB", quality=75, subsampling=1)
+    files["rgb_420_q50"] = save(rgb, "RGB", quality=50, subsampling=2)
+    files["rgb_411_q100"] = save(rgb, "RGB", quality=100, subsampling="4:1:1")
+    files["rgb_420_prog"] = save(rgb, "RGB", quality=85, subsampling=2, progressive=True)
+    files["rgb_444_prog_opt"] = save(rgb, "RGB", quality=95, subsampling=0, progressive=True, optimize=True)
+    files["rgb_420_restart"] = save(picture(45, 50, 3), "RGB", quality=80, subsampling=2, restart_marker_blocks=2)
+    files["rgb_422_restart1"] = save(picture(24, 40, 3), "RGB", quality=92, subsampling=1, restart_marker_blocks=1)
+    files["rgb_keep_rgb"] = save(rgb, "RGB", quality=90, keep_rgb=True)
+    files["rgb_q10"] = save(picture(33, 31, 3), "RGB", quality=10, subsampling=2)
+    files["grey_q80"] = save(picture(31, 22, 1), "L", quality=80)
+    files["grey_prog"] = save(picture(17, 16, 1), "L", quality=60, progressive=True)
+    files["cmyk_q85"] = save(picture(19, 23, 4), "CMYK", quality=85)
+    files["cmyk_prog"] = save(picture(16, 16, 4), "CMYK", quality=70, progressive=True)
+    files["one_pixel"] = save(picture(1, 1, 3), "RGB", quality=90)
+    files["one_block"] = save(picture(8, 8, 3), "RGB", quality=90, subsampling=2)
+    files["wide"] = save(picture(9, 70, 3), "RGB", quality=88, subsampling=2)
+    return files
+
+
+def make_jpeg_decode(ref):
+    files = jpeg_fixture_files()
+    out = {}
+    for name, data in files.items():
+        out[name + "/bytes"] = np.frombuffer(data, dtype=np.uint8)
+        for req in range(5):
+            arr, n = ref.load(data, req)
+            assert arr is not None, (name, req, n)
+            out[f"{name}/req{req}"] = arr
+            out[f"{name}/n{req}"] = np.array([n], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "jpeg_decode.npz"), **out)
+    print("jpeg_decode.npz:", len(files), "files")
+
+
 if __name__ == "__main__":
     make_frames()
     ref = stb_ref.load()
@@ -212,3 +270,4 @@ if __name__ == "__main__":
         sys.exit(1)
     make_png_decode(ref)
     make_png_encode(ref)
+    make_jpeg_decode(ref)

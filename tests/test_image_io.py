@@ -58,6 +58,49 @@ def test_decode_matches_reference_stb_live(hmrm, stb_ref):
             assert n2 == n and np.array_equal(arr, exp), (name, req)
 
 
+def test_jpeg_decode_matches_reference_stb_golden(hmrm):
+    """JPEG maps (README.md: "any format supported by stb_image.h: JPEG, ..."; sample_config.txt uses
+    .jpg): IDCT, chroma upsampling and colour conversion must be stb's, pixel for pixel."""
+    data = np.load(os.path.join(GOLDEN, "jpeg_decode.npz"))
+    checked = 0
+    for name in _names(data):
+        blob = data[name + "/bytes"].tobytes()
+        for req in range(5):
+            arr, n = hmrm.image_load_memory(blob, req)
+            assert n == int(data[f"{name}/n{req}"][0]), (name, req)
+            assert arr.shape == data[f"{name}/req{req}"].shape and np.array_equal(arr, data[f"{name}/req{req}"]), (name, req)
+            checked += 1
+    assert checked >= 80
+
+
+def test_jpeg_decode_matches_reference_stb_live(hmrm, stb_ref):
+    if stb_ref is None:
+        pytest.skip("oracle/_ref not built; golden vectors cover it")
+    pytest.importorskip("PIL")
+    import make_golden
+    files = make_golden.jpeg_fixture_files()
+    for name, blob in files.items():
+        for req in range(5):
+            exp, n = stb_ref.load(blob, req)
+            arr, n2 = hmrm.image_load_memory(blob, req)
+            assert n2 == n and np.array_equal(arr, exp), (name, req)
+    # a truncated file is refused by both
+    blob = files["rgb_420_q50"]
+    assert stb_ref.load(blob[: len(blob) // 2], 3)[0] is None
+    with pytest.raises(hmrm.HmrmError):
+        hmrm.image_load_memory(blob[: len(blob) // 2], 3)
+
+
+def test_jpeg_heightmap_through_config(hmrm, tmp_path):
+    """`heightmap x.jpg` / `colormap x.jpg` as in the reference's sample_config.txt."""
+    data = np.load(os.path.join(GOLDEN, "jpeg_decode.npz"))
+    p = tmp_path / "map.jpg"
+    p.write_bytes(data["rgb_420_q50/bytes"].tobytes())
+    cfg = hmrm.Config().consume_string(f"heightmap {p}\ncolormap {p}\n")
+    assert np.array_equal(cfg.height_rgb(), data["rgb_420_q50/req3"])
+    assert np.array_equal(cfg.color_rgba(), data["rgb_420_q50/req4"])
+
+
 def test_decode_large_random_png_roundtrip(hmrm, stb_ref):
     """A 300x200 map-like image through zlib level 9 (dynamic Huffman, long matches)."""
     import struct
