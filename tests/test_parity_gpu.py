@@ -307,3 +307,86 @@ def test_c4_orthographic_8192_subsampled(gpu, oracle):
     assert np.array_equal(steps[rows].astype(np.int64), osteps[rows])
     assert np.array_equal(_bits(entry[rows]), _bits(oentry[rows]))
     scene.close()
+
+
+def test_exact_tie_steps_and_many_binades(gpu, oracle):
+    """Orthographic rays along +x with step_dist = 0.25 + 2^-43: in the binade [1024, 2048)
+    (ulp 2^-42) every addition x + s is an exact rounding tie, in [512, 1024) it is exact, in
+    [2048, 4096) it rounds normally -- the leap arithmetic must reproduce the sequential sums
+    across all of them (and across ~12 smaller binades near x = 0)."""
+    rng = np.random.RandomState(9)
+    mw, mh = 4096, 16
+    rgb = np.repeat(rng.randint(0, 40, size=(mh, mw, 1)).astype(np.uint8), 3, axis=2)
+    rgb[:, 3900:3910] = 255  # a wall near the far end stops every ray
+    cmap = rng.randint(0, 256, size=(mh, mw, 4)).astype(np.uint8)
+    cmap[:, :, 3] = 255
+    params = gpu.SceneParams.make(0.0, 8.0, grid_width=1.0)
+    sd = 0.25 + 2.0 ** -43
+    cam = gpu.Camera.make(width=16, height=12, projection=3, hang=0.0, vang=gpu.degrees_to_rads(90),
+                          pos=(-3.0, -8.0, 4.0), ortho_width=0.45, step_dist=sd, bg=(0, 0, 0))
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    ofb, total, capped, osteps, oentry = oracle.render(oracle.make_cfg(cam, params, mw, mh), heights, cmap, per_pixel=True)
+    assert capped == 0 and osteps.max() > 10000
+    for variant in KERNEL_VARIANTS:
+        with kernel_variant(variant):
+            fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
+        assert np.array_equal(fb, ofb) and np.array_equal(steps.astype(np.int64), osteps), variant
+        if variant == "leap":
+            assert st.leaped_steps > 0.9 * st.steps, "the leap path was not exercised"
+    scene.close()
+
+
+@pytest.mark.parametrize("gw,sd", [(0.3, 0.15), (0.05, 0.02), (3.0, 0.7)])
+def test_general_grid_width_full_frame(gpu, oracle, gw, sd):
+    """grid_width that is not a power of two: cell = trunc(x * fl(1/gw)) with the true division only
+    near integer boundaries must equal trunc(x / gw) everywhere (1024^2 map, 960x540, all rays)."""
+    wl = gpu.synth.WORKLOADS["C2"]
+    rgb, cmap = gpu.synth.synth_maps(wl.map_size)
+    s = wl.map_size * gw
+    params = gpu.SceneParams.make(0.0, s / 16.0, grid_width=gw)
+    cam = gpu.Camera.make(width=960, height=540, projection=1, hfov=gpu.degrees_to_rads(90),
+                          hang=gpu.degrees_to_rads(-45), vang=gpu.degrees_to_rads(115),
+                          pos=(-s / 8.0, s / 8.0, s / 4.0), step_dist=sd, bg=(0, 0, 0))
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    ofb, total, capped, osteps, _ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap,
+                                                   per_pixel=True)
+    fb, st, steps, _ = scene.render_stats(cam, per_pixel=True)
+    assert capped == 0 and np.array_equal(fb, ofb) and np.array_equal(steps.astype(np.int64), osteps)
+    assert st.steps == total and st.leaped_steps > 0
+    scene.close()
+
+
+def test_degenerate_parameters_agree_with_oracle(gpu, oracle):
+    """Negative / huge step_dist, camera below the map, inverted height range: nothing special-cased
+    in the reference, so whatever its loop does the kernels must do too (within the step cap)."""
+    rgb, cmap = scenes.small_maps(48, 48, 91)
+    base = dict(width=40, height=30, projection=1, hfov=gpu.degrees_to_rads(85), hang=gpu.degrees_to_rads(-45),
+                vang=gpu.degrees_to_rads(118), pos=(-8.0, 8.0, 20.0), bg=(1, 2, 3))
+    trials = [
+        (gpu.SceneParams.make(0.0, 6.0, grid_width=1.0), dict(step_dist=-0.5)),
+        (gpu.SceneParams.make(0.0, 6.0, grid_width=1.0), dict(step_dist=1e6)),
+        (gpu.SceneParams.make(0.0, 6.0, grid_width=1.0), dict(step_dist=1e-3)),
+        (gpu.SceneParams.make(6.0, 0.0, grid_width=1.0), dict(step_dist=0.5)),           # max < min
+        (gpu.SceneParams.make(0.0, 6.0, grid_width=1.0), dict(step_dist=0.5, pos=(10.0, -10.0, -5.0), vang=gpu.degrees_to_rads(60))),
+        (gpu.SceneParams.make(0.0, 6.0, grid_width=-1.0), dict(step_dist=0.5)),          # box folds over
+    ]
+    os.environ["HMRM_STEP_CAP"] = "200000"
+    try:
+        for params, over in trials:
+            kw = dict(base)
+            kw.update(over)
+            cam = gpu.Camera.make(**kw)
+            scene = gpu.Scene(rgb, cmap, params)
+            heights = oracle.update_heightmap(rgb, params)
+            ofb, total, capped, osteps, _ = oracle.render(oracle.make_cfg(cam, params, 48, 48, step_cap=200000),
+                                                           heights, cmap, per_pixel=True)
+            for variant in KERNEL_VARIANTS:
+                with kernel_variant(variant):
+                    fb, st, steps, _ = scene.render_stats(cam, per_pixel=True, allow_capped=True)
+                assert np.array_equal(fb, ofb), (over, variant)
+                assert st.capped == capped and st.steps == total, (over, variant)
+            scene.close()
+    finally:
+        del os.environ["HMRM_STEP_CAP"]
