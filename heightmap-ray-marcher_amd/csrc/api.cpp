@@ -65,8 +65,8 @@ struct hmrm_scene {
 	uint32_t *d_cmap = nullptr; // W*H    colormap_buf as packed RGBA (hmap.cpp:59)
 	double *d_thr = nullptr;    // W*H    heightmap_buf[i] + min_height
 	double thr_max = 0.0;
-	float *d_mip[4] = {nullptr, nullptr, nullptr, nullptr}; // window maxima over d_thr: 4/16/64/256-cell windows every 2/8/32/128 cells
-	int32_t mip_w[4] = {0, 0, 0, 0}, mip_h[4] = {0, 0, 0, 0};
+	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/16/64/256-cell windows every 2/8/32/128 cells
+	int32_t mip_w[4] = {0, 0, 0, 0}, mip_h[4] = {0, 0, 0, 0}, mip_off[4] = {0, 0, 0, 0};
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	unsigned long long *d_counters = nullptr; // 8 x u64: steps, hits, capped, max key, 4 x traversal diagnostics
@@ -181,7 +181,7 @@ int prepare_frame(hmrm_scene *s, const hmrm_camera *cam, hipStream_t stream, hmr
 	f->step_cap = default_step_cap();
 	{
 		const char *dg = getenv("HMRM_DIAG_ITERS");
-		f->diag_mode = (dg && dg[0] == '1') ? 1 : 0;
+		f->diag_mode = (dg && dg[0] >= '1' && dg[0] <= '3') ? dg[0] - '0' : 0;
 	}
 	return HMRM_OK;
 }
@@ -228,11 +228,11 @@ int prepare_frame_uncached(hmrm_scene *s, const hmrm_camera *cam, hipStream_t st
 	// per pixel instead of the step count (tools/ only)
 	{
 		const char *dg = getenv("HMRM_DIAG_ITERS");
-		f->diag_mode = (dg && dg[0] == '1') ? 1 : 0;
+		f->diag_mode = (dg && dg[0] >= '1' && dg[0] <= '3') ? dg[0] - '0' : 0;
 	}
 	for (int l = 0; l < hmrm::kMipLevels; ++l) {
-		f->mip[l] = s->d_mip[l];
-		f->mip_w[l] = s->mip_w[l];
+		f->mipbuf = s->d_mipbuf;
+		f->mip_off[l] = s->mip_off[l];
 	}
 	return HMRM_OK;
 }
@@ -244,10 +244,11 @@ int run_update_heights(hmrm_scene *s) {
 	                                     s->params.lum_b, s->params.min_height, s->params.max_height,
 	                                     false, s->d_counters + 3, s->stream));
 	// window-maximum pyramid for the exact-leap traversal (render_fast.hip)
-	HIP_TRY(hmrm::launch_build_mip0(s->d_thr, s->map_w, s->map_h, s->d_mip[0], s->mip_w[0], s->mip_h[0], s->stream));
+	HIP_TRY(hmrm::launch_build_mip0(s->d_thr, s->map_w, s->map_h, s->d_mipbuf + s->mip_off[0], s->mip_w[0],
+	                                s->mip_h[0], s->stream));
 	for (int l = 1; l < hmrm::kMipLevels; ++l)
-		HIP_TRY(hmrm::launch_build_mip_up(s->d_mip[l - 1], s->mip_w[l - 1], s->mip_h[l - 1], s->d_mip[l],
-		                                  s->mip_w[l], s->mip_h[l], s->stream));
+		HIP_TRY(hmrm::launch_build_mip_up(s->d_mipbuf + s->mip_off[l - 1], s->mip_w[l - 1], s->mip_h[l - 1],
+		                                  s->d_mipbuf + s->mip_off[l], s->mip_w[l], s->mip_h[l], s->stream));
 	unsigned long long key = 0;
 	HIP_TRY(hipMemcpyAsync(&key, s->d_counters + 3, sizeof key, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -301,7 +302,12 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 			const int stride = 1 << hmrm::kMipStrideShift[l]; // windows of 2*stride cells every stride cells
 			s->mip_w[l] = (map_w + stride - 1) / stride;
 			s->mip_h[l] = (map_h + stride - 1) / stride;
-			HIP_TRY(hipMalloc((void **)&s->d_mip[l], (size_t)s->mip_w[l] * s->mip_h[l] * sizeof(float)));
+			s->mip_off[l] = l == 0 ? 0 : s->mip_off[l - 1] + s->mip_w[l - 1] * s->mip_h[l - 1];
+		}
+		{
+			const int last = hmrm::kMipLevels - 1;
+			const size_t total = (size_t)s->mip_off[last] + (size_t)s->mip_w[last] * s->mip_h[last];
+			HIP_TRY(hipMalloc((void **)&s->d_mipbuf, total * sizeof(float)));
 		}
 		HIP_TRY(hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long)));
 		HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->stream));
@@ -334,8 +340,7 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (s->d_rgb) (void)hipFree(s->d_rgb);
 	if (s->d_cmap) (void)hipFree(s->d_cmap);
 	if (s->d_thr) (void)hipFree(s->d_thr);
-	for (int l = 0; l < hmrm::kMipLevels; ++l)
-		if (s->d_mip[l]) (void)hipFree(s->d_mip[l]);
+	if (s->d_mipbuf) (void)hipFree(s->d_mipbuf);
 	if (s->d_counters) (void)hipFree(s->d_counters);
 	if (s->d_frame) (void)hipFree(s->d_frame);
 	if (s->d_tables) (void)hipFree(s->d_tables);

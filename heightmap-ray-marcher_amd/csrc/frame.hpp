@@ -41,9 +41,10 @@ struct DevFrame {
 	int64_t step_cap;            // guard for the reference's unbounded while(true) (:1000)
 	// window-maximum pyramid over the thr table (render_fast.hip): level l holds the maximum
 	// of thr (NaN ignored: z < NaN never hits) over S x S-cell windows, S = 4, 16, 64, 256,
-	// placed every S/2 cells; floats rounded up.  mip_w = windows per row.
-	const float *mip[4];
-	int32_t mip_w[4];
+	// placed every S/2 cells; floats rounded up.  All levels live in one buffer: level l starts
+	// at mip_off[l] and has ceil(map_w / (S/2)) windows per row.
+	const float *mipbuf;
+	int32_t mip_off[4];
 	int32_t diag_mode;           // tools only: what the instrumented kernel writes per pixel
 	int32_t pad2_;
 };

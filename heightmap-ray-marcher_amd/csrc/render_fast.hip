@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
                                                      uint32_t *__restrict__ out, int64_t out_stride_px,
                                                      int tiles_x, StatsOut st) {
 	const PixelId pid = pixel_of_lane(f, rows, tiles_x);
+	const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull; // tools-only timing
 	unsigned long long my_steps = 0;
 	uint32_t my_hit = 0, my_cap = 0;
 	uint32_t dg_attempts = 0, dg_leaps = 0, dg_groups = 0; // STATS-only diagnostics
@@ -159,14 +160,17 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 			const int offx = sx < 0.0 ? 1 : 0, offy = sy > 0.0 ? 1 : 0; // gy = trunc(-y/gw) falls when y grows
 			const double gwid = (GWM == 0) ? 1.0 : f.grid_width;
 
+			// The loop body is written branch-light on purpose: a wave executes every divergent
+			// branch any of its lanes takes, and exec-mask juggling per `if` costs as much as
+			// the arithmetic it guards.  Values are computed for all lanes and selected.
 			bool done = false;
 			while (!done) {
+				bool skip_group = false;
 				// ---------------------------------------------------------- leap
 				if (LEAP) {
-					bool leaped = false;
-					if (cooldown > 0) {
-						--cooldown;
-					} else {
+					const bool attempt = cooldown == 0;
+					cooldown -= attempt ? 0 : 1;
+					if (attempt) {
 						if (STATS) ++dg_attempts;
 						if ((hi32(x) >> 20) != ax.key) axis_refresh(ax, x, sx);
 						if ((hi32(y) >> 20) != ay.key) axis_refresh(ay, y, sy);
@@ -174,91 +178,82 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 						const double qx = cell_coord<GWM>(x, f), qy = cell_coord<GWM>(-y, f);
 						const bool inb0 = qx > -1.0 && qx < wlim && qy > -1.0 && qy < hlim;
 						const bool exact = ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
-						// outcome: 0 = leaped, 1 = too close to the window maximum (go finer),
-						//          2 = out of lateral / binade room (step a group, then retry)
-						int outcome = 2;
-						if (inb0 && exact) {
-							const int gx = (int)qx, gy = (int)qy;
-							double m;
-							int wx0, wy0, wspan_x, wspan_y;
-							if (lev == kTopLevel) {
-								m = f.thr_max;
-								wx0 = 0; wy0 = 0; wspan_x = f.map_w; wspan_y = f.map_h;
-							} else {
-								const int hs = 2 * lev + 1; // log2 of the window stride S/2
-								int ix = (gx >> hs) - offx, iy = (gy >> hs) - offy;
-								ix = ix < 0 ? 0 : ix;
-								iy = iy < 0 ? 0 : iy;
-								const float *mp = lev == 0 ? f.mip[0] : (lev == 1 ? f.mip[1] : (lev == 2 ? f.mip[2] : f.mip[3]));
-								const int mw = lev == 0 ? f.mip_w[0] : (lev == 1 ? f.mip_w[1] : (lev == 2 ? f.mip_w[2] : f.mip_w[3]));
-								m = (double)mp[iy * mw + ix];
-								wx0 = ix << hs; wy0 = iy << hs;
-								wspan_x = wspan_y = 2 << hs;
-							}
-							if (!(z >= m)) {
-								outcome = 1;
-							} else {
-								// estimates of the steps left before each constraint bites; rdel is signed
-								// like the motion, so every quotient is >= 0.  All verified below.
-								const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;      // x edge ahead
-								const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid;     // y edge ahead
-								double room = (ax.lim - x) * ax.rdel;
-								room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
-								room = __builtin_fmin(room, (az.lim - z) * az.rdel);
-								if (sx != 0.0) room = __builtin_fmin(room, (ex - x) * ax.rdel);
-								if (sy != 0.0) room = __builtin_fmin(room, (ey - y) * ay.rdel);
-								room = __builtin_fmin(room, (double)budget);
-								double room_z = 0x1p40;
-								if (sz < 0.0) room_z = (m - z) * az.rdel;
-								const bool z_bound = room_z < room;
-								room = __builtin_fmin(room, room_z);
-								const int n = (int)(room * 0.998) - 1;
-								outcome = z_bound ? 1 : 2;
-								if (n >= kMinLeap) {
-									const double nn = (double)n;
-									const double xn = x + nn * ax.delta, yn = y + nn * ay.delta, zn = z + nn * az.delta;
-									const double qxn = cell_coord<GWM>(xn, f), qyn = cell_coord<GWM>(-yn, f);
-									bool ok = qxn > -1.0 && qxn < wlim && qyn > -1.0 && qyn < hlim;
-									ok = ok && (unsigned)((int)qxn - wx0) < (unsigned)wspan_x &&
-									     (unsigned)((int)qyn - wy0) < (unsigned)wspan_y;
-									ok = ok && zn >= m;
-									ok = ok && axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
-									if (ok) {
-										x = xn; y = yn; z = zn;
-										budget -= n;
-										if (STATS) { my_steps += (unsigned)n; dg_leaped += (unsigned)n; ++dg_leaps; }
-										leaped = true;
-										outcome = z_bound ? 1 : 0;
-									}
-								}
-							}
+						const bool top = lev == kTopLevel;
+						const int gx = (int)(inb0 ? qx : 0.0), gy = (int)(inb0 ? qy : 0.0);
+						// window (ix,iy) of level lev: S = 2<<hs cells wide, every 1<<hs cells
+						const int hs = 2 * lev + 1;
+						int ix = (gx >> hs) - offx, iy = (gy >> hs) - offy;
+						ix = ix < 0 ? 0 : ix;
+						iy = iy < 0 ? 0 : iy;
+						const int mw = (f.map_w + (1 << hs) - 1) >> hs; // windows per row (as built on the host)
+						const int loff = lev == 0 ? 0 : (lev == 1 ? f.mip_off[1] : (lev == 2 ? f.mip_off[2] : f.mip_off[3]));
+						const float mf = f.mipbuf[top ? 0 : loff + iy * mw + ix];
+						const double m = top ? f.thr_max : (double)mf;
+						const int wx0 = top ? 0 : ix << hs, wy0 = top ? 0 : iy << hs;
+						const int wspan_x = top ? f.map_w : 2 << hs, wspan_y = top ? f.map_h : 2 << hs;
+						const bool above = z >= m;
+						// estimates of the steps left before each constraint bites; rdel is signed like
+						// the motion, so every quotient is >= 0.  Only estimates: verified below.
+						const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;  // x edge ahead
+						const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid; // y edge ahead
+						double room = (ax.lim - x) * ax.rdel;
+						room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
+						room = __builtin_fmin(room, (az.lim - z) * az.rdel);
+						room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
+						room = __builtin_fmin(room, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
+						room = __builtin_fmin(room, (double)budget);
+						const double room_z = sz < 0.0 ? (m - z) * az.rdel : 0x1p40;
+						const bool z_bound = room_z < room;
+						room = __builtin_fmin(room, room_z);
+						room = __builtin_fmin(__builtin_fmax(room, 0.0), 0x1p30);
+						const int n = (int)(room * 0.998) - 1;
+						const bool can = inb0 && exact && above && n >= kMinLeap;
+						// landing point and its exact verification
+						const double nn = (double)n;
+						const double xn = x + nn * ax.delta, yn = y + nn * ay.delta, zn = z + nn * az.delta;
+						const double qxn = cell_coord<GWM>(xn, f), qyn = cell_coord<GWM>(-yn, f);
+						const bool inbn = qxn > -1.0 && qxn < wlim && qyn > -1.0 && qyn < hlim;
+						const int gxn = (int)(inbn ? qxn : 0.0), gyn = (int)(inbn ? qyn : 0.0);
+						const bool ok = can && inbn && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
+						                (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
+						                axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
+						x = ok ? xn : x;
+						y = ok ? yn : y;
+						z = ok ? zn : z;
+						budget -= ok ? n : 0;
+						if (STATS) {
+							my_steps += ok ? (unsigned)n : 0u;
+							dg_leaped += ok ? (unsigned)n : 0u;
+							dg_leaps += ok ? 1u : 0u;
 						}
 						// level policy (performance only; any policy gives the same pixels):
-						//   window crossed (0)      -> coarser next time
-						//   height bound hit (1)    -> finer; without a jump retry at once (no progress is
-						//                              lost, the level strictly decreases); at the finest
-						//                              level march two groups before looking again
-						//   no lateral/binade room  -> coarser (a bigger window has more room), and march
-						//   or not exact (2)           with a growing pause while attempts keep failing
-						bool retry = false;
-						if (outcome == 0) {
+						//   window crossed                    -> coarser next time
+						//   height bound was the limit        -> finer; without a jump retry at once (the
+						//     (z < max, or z-room smallest)      level strictly decreases); at the finest
+						//                                        level march two groups before looking again
+						//   no lateral/binade room, not exact -> coarser (a bigger window has more room),
+						//                                        growing pause while attempts keep failing
+						const bool height_limited = inb0 && exact && (!above || z_bound);
+						const int coarser = lev >= kMipLevels - 1 ? kMipLevels - 1 : lev + 1;
+						const int finer = top ? kMipLevels - 1 : (lev > 0 ? lev - 1 : 0);
+						const bool at_finest = lev == 0;
+						if (ok && !z_bound) {
 							fails = 0;
-							if (lev < kMipLevels - 1) ++lev;
-						} else if (outcome == 1) {
-							if (leaped) fails = 0;
-							if (lev == kTopLevel) lev = kMipLevels - 1;
-							else if (lev > 0) { --lev; retry = !leaped; }
-							else if (!leaped) cooldown = 1;
+							lev = coarser;
+						} else if (height_limited) {
+							fails = ok ? 0 : fails;
+							skip_group = !ok && !at_finest; // retry one level down without marching
+							cooldown = (!ok && at_finest) ? 1 : 0;
+							lev = finer;
 						} else {
-							if (lev == kTopLevel) lev = kMipLevels - 1;
-							else if (lev < kMipLevels - 1) ++lev;
 							cooldown = fails < 3 ? fails : 3;
 							++fails;
+							lev = coarser;
 						}
-						if (retry) continue;
+						skip_group = skip_group || ok; // after a jump look at the next window straight away
 					}
-					if (leaped) continue; // try the next window straight away
 				}
+				if (skip_group) continue;
 
 				// --------------------------------------------- speculative group
 				if (STATS) ++dg_groups;
@@ -282,24 +277,41 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 				}
 #pragma unroll
 				for (int j = 0; j < kGroup; ++j) T[j] = thr[cell[j]]; // hmap.cpp:1013-1014 (+ c0.z)
-#pragma unroll
-				for (int j = 0; j < kGroup; ++j) {
-					if (!inb[j]) { done = true; break; }
-					if (budget <= 0) { my_cap = 1; done = true; break; }
-					--budget;
-					if (STATS) my_steps += 1;
-					if (Z[j] < T[j]) { // hmap.cpp:1016
-						rgba = shade_hit(f, cmap[cell[j]]);
+				if (budget >= kGroup) {
+					// in order: the first position that leaves the grid (:1006) or hits (:1016) ends the ray
+					const bool h0 = inb[0] && Z[0] < T[0], h1 = inb[1] && Z[1] < T[1];
+					const bool h2 = inb[2] && Z[2] < T[2], h3 = inb[3] && Z[3] < T[3];
+					const bool s0 = !inb[0] || h0, s1 = !inb[1] || h1, s2 = !inb[2] || h2, s3 = !inb[3] || h3;
+					const int first = s0 ? 0 : (s1 ? 1 : (s2 ? 2 : (s3 ? 3 : 4)));
+					const bool hit = s0 ? h0 : (s1 ? h1 : (s2 ? h2 : (s3 ? h3 : false)));
+					const int hit_cell = s0 ? cell[0] : (s1 ? cell[1] : (s2 ? cell[2] : cell[3]));
+					const int taken = first + (hit ? 1 : 0); // loads the reference executed in this group
+					budget -= taken;
+					if (STATS) my_steps += (unsigned)taken;
+					done = first < kGroup;
+					if (hit) {
+						rgba = shade_hit(f, cmap[hit_cell]);
 						real_hit = true;
-						done = true;
-						break;
+					}
+				} else {
+					// (almost never) close to the step cap: one position at a time, cap checked per step
+#pragma unroll
+					for (int j = 0; j < kGroup; ++j) {
+						if (!inb[j]) { done = true; break; }
+						if (budget <= 0) { my_cap = 1; done = true; break; }
+						--budget;
+						if (STATS) my_steps += 1;
+						if (Z[j] < T[j]) { // hmap.cpp:1016
+							rgba = shade_hit(f, cmap[cell[j]]);
+							real_hit = true;
+							done = true;
+							break;
+						}
 					}
 				}
-				if (!done) {
-					x = X[kGroup - 1] + sx;
-					y = Y[kGroup - 1] + sy;
-					z = Z[kGroup - 1] + sz;
-				}
+				x = X[kGroup - 1] + sx;
+				y = Y[kGroup - 1] + sy;
+				z = Z[kGroup - 1] + sz;
 			}
 		}
 
@@ -310,6 +322,8 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 			st.steps_per_pixel[(int64_t)pid.py * f.screen_w + pid.px] =
 			    f.diag_mode == 1 ? ((dg_attempts > 0xffffu ? 0xffffu : dg_attempts) << 16) |
 			                       (dg_groups > 0xffffu ? 0xffffu : dg_groups)
+			    : f.diag_mode == 2 ? (uint32_t)(__builtin_amdgcn_s_memtime() - t_start) // wave cycles
+			    : f.diag_mode == 3 ? (uint32_t)t_start
 			                 : (my_steps > 0xffffffffull ? 0xffffffffu : (uint32_t)my_steps);
 	}
 	publish_counters<STATS>(st, my_steps, my_hit, my_cap);
