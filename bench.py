@@ -111,9 +111,13 @@ def main():
     torch.cuda.set_device(local_rank)
     hmrm.set_device(local_rank)
     dist = None
-    if world > 1:
+    # HMRM_FORCE_DIST=1 runs the torch.distributed (RCCL) code path even with one rank, so that
+    # the N>1 plumbing can be exercised on a single-GPU box
+    force_dist = os.environ.get("HMRM_FORCE_DIST", "") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -129,7 +133,7 @@ def main():
     frame_steps, frame_rays, frame_hits = int(st.steps), int(st.rays), int(st.hits)
     algo_bytes = 8 * frame_steps + 4 * frame_rays + 4 * frame_hits
 
-    if world == 1 or args.mode == "frames":
+    if (world == 1 and not force_dist) or args.mode == "frames":
         out = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
 
         def step():
@@ -175,7 +179,7 @@ def main():
 
     # correctness of what was just timed: the frame on rank 0 equals the single-GPU frame
     if rank == 0:
-        got = (result["frame"] if (world > 1 and args.mode == "strips") else out).cpu().numpy()
+        got = (result["frame"] if ((world > 1 or force_dist) and args.mode == "strips") else out).cpu().numpy()
         if not np.array_equal(got, fb_ref):
             raise SystemExit("bench.py: timed path produced a different frame than hmrm_render_stats")
 

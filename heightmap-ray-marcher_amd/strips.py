@@ -77,7 +77,7 @@ def render_frame_distributed(plan: BandPlan, rank: int, render_rows, dist, strip
     reassembled (height, width, 4) frame; other ranks return None.
     """
     render_rows(strip, plan.band_rows, rank, plan.world)
-    if plan.world == 1:
+    if plan.world == 1 and block is None:
         return reassemble_torch(plan, strip.unsqueeze(0))
     dist.gather(strip, gather_list=list(block.unbind(0)) if rank == 0 else None, dst=0)
     if rank != 0:
