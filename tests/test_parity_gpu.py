@@ -390,3 +390,56 @@ def test_degenerate_parameters_agree_with_oracle(gpu, oracle):
             scene.close()
     finally:
         del os.environ["HMRM_STEP_CAP"]
+
+
+def test_random_cameras_and_parameters_fuzz(gpu, oracle):
+    """Seeded fuzz: random projection / pose / fov / step / grid width / height range on random
+    maps, production kernel vs oracle (frame + per-ray step counts).  The leap path has many
+    data-dependent corners (window edges, binade crossings, z-limited jumps); this sweeps them."""
+    rng = np.random.RandomState(20261003)
+    os.environ["HMRM_STEP_CAP"] = "400000"
+    checked = leaped = 0
+    try:
+        for trial in range(48):
+            mw, mh = int(rng.choice([48, 96, 160, 257])), int(rng.choice([48, 96, 131]))
+            rgb, cmap = scenes.small_maps(mw, mh, 1000 + trial, color_heights=bool(trial % 3 == 0))
+            gw = float(rng.choice([1.0, 0.5, 0.05, 0.3, 2.0, 1.7]))
+            lo = float(rng.choice([0.0, 0.0, -1.5, 2.0]))
+            hi = lo + float(rng.uniform(0.5, 0.3 * mw)) * gw
+            params = gpu.SceneParams.make(lo, hi, grid_width=gw)
+            ext_x, ext_y = mw * gw, mh * gw
+            proj = int(rng.choice([1, 2, 3]))
+            # camera somewhere around / above the map, looking roughly at its centre
+            ang = rng.uniform(0, 2 * np.pi)
+            dist = rng.uniform(0.2, 1.6) * max(ext_x, ext_y)
+            pos = (ext_x / 2 + dist * np.cos(ang), -ext_y / 2 + dist * np.sin(ang), hi + rng.uniform(-0.5, 2.0) * (hi - lo + gw))
+            hang = float(np.arctan2(-ext_y / 2 - pos[1], ext_x / 2 - pos[0]) + rng.uniform(-0.4, 0.4))
+            vang = float(gpu.degrees_to_rads(rng.uniform(60, 170)))
+            cam = gpu.Camera.make(width=int(rng.randint(17, 90)), height=int(rng.randint(9, 70)), projection=proj,
+                                  hfov=float(gpu.degrees_to_rads(rng.uniform(30, 175))), hang=hang, vang=vang, pos=pos,
+                                  ortho_width=float(rng.uniform(0.2, 3.0) * gw),
+                                  step_dist=float(rng.choice([0.05, 0.1, 0.25, 0.5, 1.0, 0.37]) * gw),
+                                  bg=tuple(int(v) for v in rng.randint(0, 256, size=3)))
+            heights = oracle.update_heightmap(rgb, params)
+            ofb, total, capped, osteps, oentry = oracle.render(oracle.make_cfg(cam, params, mw, mh, step_cap=400000),
+                                                               heights, cmap, per_pixel=True)
+            scene = gpu.Scene(rgb, cmap, params)
+            fb, st, steps, entry = scene.render_stats(cam, per_pixel=True, allow_capped=True)
+            label = (trial, proj, gw, cam.step_dist)
+            assert np.array_equal(_bits(entry), _bits(oentry)), label
+            assert np.array_equal(fb, ofb), label
+            if capped == 0:
+                assert np.array_equal(steps.astype(np.int64), osteps) and st.steps == total, label
+            assert st.capped == capped, label
+            try:
+                plain = scene.render(cam)
+            except gpu.HmrmError as e:
+                assert e.code == gpu.HMRM_E_NOTERM and capped > 0
+            else:
+                assert np.array_equal(plain, ofb), label
+            leaped += st.leaped_steps
+            checked += 1
+            scene.close()
+    finally:
+        del os.environ["HMRM_STEP_CAP"]
+    assert checked == 48 and leaped > 0
