@@ -15,13 +15,20 @@ struct Image {
 	std::vector<uint8_t> px;  // row-major, top-left origin, 8 bits per channel
 };
 
-// Decode PNG, JPEG or binary PNM from memory into 8-bit channels, converted to
+// Decode PNG, JPEG, BMP, TGA or binary PNM from memory into 8-bit channels, converted to
 // req_comp (0 = keep) the way stb_image v2.27's stbi_load does.  On failure
 // returns false and sets err to a short reason.
 bool decode_image(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
 bool load_image_file(const char *path, int req_comp, Image *out, std::string *err);
 // Baseline / progressive JPEG (jpeg_decode.cpp), same conventions.
 bool decode_jpeg(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
+// Windows BMP and Truevision TGA (bmp_tga_decode.cpp), same conventions.
+bool looks_like_bmp(const uint8_t *bytes, size_t len);
+bool decode_bmp(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
+bool looks_like_tga(const uint8_t *bytes, size_t len);
+bool decode_tga(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
+// stb's channel conversion table for 8-bit data (grey<->RGB, alpha add/drop, luma).
+std::vector<uint8_t> convert_channels8(const std::vector<uint8_t> &src, int from, int to, size_t npix);
 
 // PNG encoder producing the same bytes as stb_image_write v1.16's
 // stbi_write_png_to_mem at its defaults (compression level 8, filter chosen per

@@ -8,6 +8,7 @@
   png_decode.npz  small PNG/PNM files (bytes) and, for req_comp 0..4, the pixels
                   the REFERENCE's own stb_image v2.27 decodes from them
                   (oracle/_ref/libstb_ref.so, built from /root/reference/vendor).
+  jpeg_decode.npz / bmp_tga_decode.npz  the same for JPEG, BMP and TGA files
   png_encode.json sha256 + length of the files the REFERENCE's stb_image_write
                   v1.16 writes for seeded test images.
 
@@ -248,6 +249,88 @@ def jpeg_fixture_files():
     return files
 
 
+def bmp_tga_fixture_files():
+    """BMP and TGA variants: written with Pillow where it can, hand-assembled otherwise
+    (16-bit 5-5-5 / 5-6-5, 32-bit default / all-zero alpha / shuffled 8-8-8 bitfields, top-down,
+    OS/2 header, 4-bit palette; TGA 15/16-bit, 16-bit palette entries, RLE, top-left origin)."""
+    import io
+    from PIL import Image
+    rng = np.random.RandomState(777)
+
+    def pil(arr, mode, fmt, **kw):
+        buf = io.BytesIO()
+        Image.fromarray(arr, mode).save(buf, fmt, **kw)
+        return buf.getvalue()
+
+    files = {}
+    rgb = rng.randint(0, 256, size=(13, 17, 3)).astype(np.uint8)
+    rgba = rng.randint(0, 256, size=(9, 11, 4)).astype(np.uint8)
+    grey = rng.randint(0, 256, size=(10, 7)).astype(np.uint8)
+    files["bmp24"] = pil(rgb, "RGB", "BMP")
+    files["bmp32"] = pil(rgba, "RGBA", "BMP")
+    files["bmp8"] = pil(grey, "L", "BMP")
+    quant = Image.fromarray(rgb, "RGB").quantize(16)
+    b = io.BytesIO(); quant.save(b, "BMP"); files["bmp_pal"] = b.getvalue()
+    b = io.BytesIO(); Image.fromarray((grey > 128).astype(np.uint8) * 255, "L").convert("1").save(b, "BMP")
+    files["bmp1"] = b.getvalue()
+
+    def bmp_raw(w, h, bpp, rows, masks=None, hsz=40, topdown=False, palette=b"", compress=0):
+        data = b"".join(r + b"\0" * ((-len(r)) & 3) for r in rows)
+        extra = b"".join(struct.pack("<I", m) for m in masks) if masks else b""
+        if hsz == 12:
+            hdr = struct.pack("<IHHHH", 12, w, h, 1, bpp)
+        else:
+            hdr = struct.pack("<IiiHHIIiiII", 40, w, -h if topdown else h, 1, bpp, compress, len(data), 2835, 2835, 0, 0)
+        off = 14 + len(hdr) + len(extra) + len(palette)
+        return b"BM" + struct.pack("<IHHI", off + len(data), 0, 0, off) + hdr + extra + palette + data
+
+    w, h = 7, 5
+    px16 = rng.randint(0, 65536, size=(h, w)).astype(np.uint16)
+    px32 = rng.randint(0, 2 ** 32, size=(h, w), dtype=np.uint64).astype(np.uint32)
+    rows24 = lambda: [rng.randint(0, 256, size=w * 3).astype(np.uint8).tobytes() for _ in range(h)]
+    files["bmp16_555"] = bmp_raw(w, h, 16, [px16[r].tobytes() for r in range(h)])
+    files["bmp16_565"] = bmp_raw(w, h, 16, [px16[r].tobytes() for r in range(h)], masks=(0xF800, 0x07E0, 0x001F), compress=3)
+    files["bmp32_default"] = bmp_raw(w, h, 32, [px32[r].tobytes() for r in range(h)])
+    files["bmp32_alpha0"] = bmp_raw(w, h, 32, [(px32[r] & 0x00FFFFFF).tobytes() for r in range(h)])
+    files["bmp32_bitfields"] = bmp_raw(w, h, 32, [px32[r].tobytes() for r in range(h)],
+                                       masks=(0x0000FF00, 0x00FF0000, 0xFF000000), compress=3)
+    files["bmp24_topdown"] = bmp_raw(w, h, 24, rows24(), topdown=True)
+    files["bmp24_os2"] = bmp_raw(w, h, 24, rows24(), hsz=12)
+    files["bmp4"] = bmp_raw(w, h, 4, [rng.randint(0, 256, size=(w + 1) // 2).astype(np.uint8).tobytes() for _ in range(h)],
+                            palette=bytes(rng.randint(0, 256, size=16 * 4).astype(np.uint8)))
+    files["tga24"] = pil(rgb, "RGB", "TGA")
+    files["tga32"] = pil(rgba, "RGBA", "TGA")
+    files["tga8"] = pil(grey, "L", "TGA")
+    files["tga24_rle"] = pil(np.repeat(rgb[:, :6], 3, axis=1).copy(), "RGB", "TGA", compression="tga_rle")
+    files["tga32_rle_top"] = pil(rgba, "RGBA", "TGA", compression="tga_rle", orientation=1)
+    b = io.BytesIO(); quant.save(b, "TGA"); files["tga_pal"] = b.getvalue()
+    files["tga_la"] = pil(rng.randint(0, 256, size=(6, 5, 2)).astype(np.uint8), "LA", "TGA")
+
+    def tga_raw(w, h, bpp, data, imgtype=2, desc=0, pal=b"", palbits=0):
+        entries = len(pal) // (max(palbits, 8) // 8) if pal else 0
+        return struct.pack("<BBBHHBHHHHBB", 0, 1 if pal else 0, imgtype, 0, entries, palbits, 0, 0, w, h, bpp, desc) + pal + data
+
+    files["tga16"] = tga_raw(w, h, 16, px16.tobytes())
+    files["tga15_top"] = tga_raw(w, h, 15, px16.tobytes(), desc=0x20)
+    files["tga_pal16"] = tga_raw(w, h, 8, rng.randint(0, 8, size=w * h).astype(np.uint8).tobytes(), imgtype=1,
+                                 pal=rng.randint(0, 65536, size=8).astype(np.uint16).tobytes(), palbits=16)
+    return files
+
+
+def make_bmp_tga_decode(ref):
+    files = bmp_tga_fixture_files()
+    out = {}
+    for name, data in files.items():
+        out[name + "/bytes"] = np.frombuffer(data, dtype=np.uint8)
+        for req in range(5):
+            arr, n = ref.load(data, req)
+            assert arr is not None, (name, req, n)
+            out[f"{name}/req{req}"] = arr
+            out[f"{name}/n{req}"] = np.array([n], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "bmp_tga_decode.npz"), **out)
+    print("bmp_tga_decode.npz:", len(files), "files")
+
+
 def make_jpeg_decode(ref):
     files = jpeg_fixture_files()
     out = {}
@@ -271,3 +354,4 @@ if __name__ == "__main__":
     make_png_decode(ref)
     make_png_encode(ref)
     make_jpeg_decode(ref)
+    make_bmp_tga_decode(ref)

@@ -91,6 +91,30 @@ def test_jpeg_decode_matches_reference_stb_live(hmrm, stb_ref):
         hmrm.image_load_memory(blob[: len(blob) // 2], 3)
 
 
+def test_bmp_tga_decode_matches_reference_stb(hmrm, stb_ref):
+    """BMP / TGA maps (README.md "Options": "... TGA, BMP ..."): golden vectors from the reference's stb,
+    plus the live comparison where that build exists."""
+    data = np.load(os.path.join(GOLDEN, "bmp_tga_decode.npz"))
+    checked = 0
+    for name in _names(data):
+        blob = data[name + "/bytes"].tobytes()
+        for req in range(5):
+            arr, n = hmrm.image_load_memory(blob, req)
+            assert n == int(data[f"{name}/n{req}"][0]), (name, req)
+            assert arr.shape == data[f"{name}/req{req}"].shape and np.array_equal(arr, data[f"{name}/req{req}"]), (name, req)
+            if stb_ref is not None:
+                exp, n2 = stb_ref.load(blob, req)
+                assert n2 == n and np.array_equal(arr, exp), (name, req)
+            checked += 1
+    assert checked >= 110
+    # refused like stb refuses them: RLE-compressed BMP, truncated header
+    import struct
+    rle = b"BM" + struct.pack("<IHHI", 0, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 4, 4, 1, 8, 1, 0, 0, 0, 0, 0)
+    for blob in (rle, data["bmp24/bytes"].tobytes()[:20]):
+        with pytest.raises(hmrm.HmrmError):
+            hmrm.image_load_memory(blob, 3)
+
+
 def test_jpeg_heightmap_through_config(hmrm, tmp_path):
     """`heightmap x.jpg` / `colormap x.jpg` as in the reference's sample_config.txt."""
     data = np.load(os.path.join(GOLDEN, "jpeg_decode.npz"))
