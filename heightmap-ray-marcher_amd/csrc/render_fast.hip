@@ -65,6 +65,19 @@ __device__ __forceinline__ double cell_coord(double v, const DevFrame &f) {
 	return q;
 }
 
+// (int)q exactly as the reference's x86 build evaluates it for the range test of hmap.cpp:1001-
+// 1011, without C++'s undefined behaviour for out-of-range values: v_cvt_i32_f64 truncates
+// toward zero and saturates, so q in (-1,0) gives 0 (inside, as on the CPU), q <= -1 a negative
+// index, |q| >= 2^31 and +-inf give INT_MIN / INT_MAX (outside; cvttsd2si gives INT_MIN: also
+// outside).  Only NaN would differ (0 here, INT_MIN there), and a position cannot be NaN inside
+// the loop: the entry point is checked once, and sums of finite or infinite steps of one sign
+// never produce NaN.
+__device__ __forceinline__ int cvt_i32_sat(double q) {
+	int r;
+	asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(q));
+	return r;
+}
+
 // Exact-stepping state of one coordinate inside its current binade.
 struct Axis {
 	double delta;  // p_{k+1} - p_k for every p of the binade (valid iff key matches)
@@ -145,8 +158,10 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 			const double sx = f.step_dist * ray.dx; // hmap.cpp:1037, loop invariant
 			const double sy = f.step_dist * ray.dy;
 			const double sz = f.step_dist * ray.dz;
-			const double wlim = (double)f.map_w, hlim = (double)f.map_h;
-			int64_t budget = f.step_cap;
+			const unsigned wlim = (unsigned)f.map_w, hlim = (unsigned)f.map_h;
+			int budget = f.step_cap > 0x7fffffff ? 0x7fffffff : (int)f.step_cap;
+			// (int)NaN is INT_MIN on the reference's CPU: the first range test fails, the ray misses
+			const bool entry_nan = x != x || y != y;
 
 			// leap state
 			int lev = kTopLevel; // rays enter the box above everything: first try the whole-map bound
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 			// The loop body is written branch-light on purpose: a wave executes every divergent
 			// branch any of its lanes takes, and exec-mask juggling per `if` costs as much as
 			// the arithmetic it guards.  Values are computed for all lanes and selected.
-			bool done = false;
+			bool done = entry_nan;
 			while (!done) {
 				bool skip_group = false;
 				// ---------------------------------------------------------- leap
@@ -176,10 +191,10 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 						if ((hi32(y) >> 20) != ay.key) axis_refresh(ay, y, sy);
 						if ((hi32(z) >> 20) != az.key) axis_refresh(az, z, sz);
 						const double qx = cell_coord<GWM>(x, f), qy = cell_coord<GWM>(-y, f);
-						const bool inb0 = qx > -1.0 && qx < wlim && qy > -1.0 && qy < hlim;
+						const int gx = cvt_i32_sat(qx), gy = cvt_i32_sat(qy);
+						const bool inb0 = (unsigned)gx < wlim && (unsigned)gy < hlim;
 						const bool exact = ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
 						const bool top = lev == kTopLevel;
-						const int gx = (int)(inb0 ? qx : 0.0), gy = (int)(inb0 ? qy : 0.0);
 						// window (ix,iy) of level lev: S = 2<<hs cells wide, every 1<<hs cells
 						const int hs = 2 * lev + 1;
 						int ix = (gx >> hs) - offx, iy = (gy >> hs) - offy;
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 						iy = iy < 0 ? 0 : iy;
 						const int mw = (f.map_w + (1 << hs) - 1) >> hs; // windows per row (as built on the host)
 						const int loff = lev == 0 ? 0 : (lev == 1 ? f.mip_off[1] : (lev == 2 ? f.mip_off[2] : f.mip_off[3]));
-						const float mf = f.mipbuf[top ? 0 : loff + iy * mw + ix];
+						const float mf = f.mipbuf[(top || !inb0) ? 0 : loff + iy * mw + ix];
 						const double m = top ? f.thr_max : (double)mf;
 						const int wx0 = top ? 0 : ix << hs, wy0 = top ? 0 : iy << hs;
 						const int wspan_x = top ? f.map_w : 2 << hs, wspan_y = top ? f.map_h : 2 << hs;
@@ -212,8 +227,8 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 						const double nn = (double)n;
 						const double xn = x + nn * ax.delta, yn = y + nn * ay.delta, zn = z + nn * az.delta;
 						const double qxn = cell_coord<GWM>(xn, f), qyn = cell_coord<GWM>(-yn, f);
-						const bool inbn = qxn > -1.0 && qxn < wlim && qyn > -1.0 && qyn < hlim;
-						const int gxn = (int)(inbn ? qxn : 0.0), gyn = (int)(inbn ? qyn : 0.0);
+						const int gxn = cvt_i32_sat(qxn), gyn = cvt_i32_sat(qyn);
+						const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim;
 						const bool ok = can && inbn && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
 						                (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
 						                axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
@@ -270,10 +285,9 @@ __global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const Row
 #pragma unroll
 				for (int j = 0; j < kGroup; ++j) {
 					const double qx = cell_coord<GWM>(X[j], f), qy = cell_coord<GWM>(-Y[j], f);
-					// hmap.cpp:1006-1011: (int)q >= 0 <=> q > -1 ; (int)q < N <=> q < N ; NaN -> break
-					inb[j] = qx > -1.0 && qx < wlim && qy > -1.0 && qy < hlim;
-					const int gx = (int)(inb[j] ? qx : 0.0), gy = (int)(inb[j] ? qy : 0.0);
-					cell[j] = gy * f.map_w + gx;
+					const int gx = cvt_i32_sat(qx), gy = cvt_i32_sat(qy); // hmap.cpp:1001-1004
+					inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;      // hmap.cpp:1006-1011
+					cell[j] = inb[j] ? gy * f.map_w + gx : 0;
 				}
 #pragma unroll
 				for (int j = 0; j < kGroup; ++j) T[j] = thr[cell[j]]; // hmap.cpp:1013-1014 (+ c0.z)
