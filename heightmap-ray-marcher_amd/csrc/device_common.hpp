@@ -138,7 +138,13 @@ __device__ __forceinline__ uint32_t shade_hit(const DevFrame &f, uint32_t texel)
 	return ((texel >> 24) == 0) ? pack_rgba(f.bg[0], f.bg[1], f.bg[2]) : (texel | 0xff000000u);
 }
 
-// Which pixel a lane owns: 16x16 pixel tile per workgroup, one 8x8 sub-tile per wave.
+// Which pixel a lane owns.  A wave covers kWaveW x kWaveH pixels (kWaveW * kWaveH = 64), a
+// 256-thread workgroup a 2 x 2 arrangement of waves.
+#ifndef HMRM_WAVE_W
+#define HMRM_WAVE_W 8
+#endif
+constexpr int kWaveW = HMRM_WAVE_W, kWaveH = 64 / HMRM_WAVE_W;
+constexpr int kTileW = 2 * kWaveW, kTileH = 2 * kWaveH;
 struct PixelId {
 	int px, py, lrow;
 	bool live;
@@ -148,8 +154,8 @@ __device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	PixelId p;
-	p.px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-	p.lrow = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	p.px = tile_x * kTileW + (wave & 1) * kWaveW + (lane % kWaveW);
+	p.lrow = tile_y * kTileH + (wave >> 1) * kWaveH + (lane / kWaveW);
 	if (rows.band_rows > 0) {
 		const int band = p.lrow / rows.band_rows, within = p.lrow - band * rows.band_rows;
 		p.py = (rows.band_index + band * rows.band_count) * rows.band_rows + within;

@@ -240,8 +240,8 @@ template <bool STATS>
 static hipError_t launch_render_t(const DevFrame &f, const RowMap &rows, const double *d_thr,
                                   const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                                   StatsOut st, hipStream_t stream) {
-	const int tiles_x = (f.screen_w + 15) / 16;
-	const int tiles_y = (rows.local_rows + 15) / 16;
+	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
+	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
 	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
 	const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y)), block(256);
 	switch (f.projection) {

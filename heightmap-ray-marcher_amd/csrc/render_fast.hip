@@ -40,7 +40,10 @@ namespace hmrm {
 namespace {
 
 constexpr int kGroup = 4;       // U: positions per speculative group
-constexpr int kMinLeap = 6;     // a jump shorter than this is not worth its bookkeeping
+#ifndef HMRM_MIN_LEAP
+#define HMRM_MIN_LEAP 6
+#endif
+constexpr int kMinLeap = HMRM_MIN_LEAP; // a jump shorter than this is not worth its bookkeeping
 constexpr int kTopLevel = kMipLevels; // whole-map level (thr_max, no load)
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
@@ -466,8 +469,8 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
                               bool leap, hipStream_t stream) {
-	const int tiles_x = (f.screen_w + 15) / 16;
-	const int tiles_y = (rows.local_rows + 15) / 16;
+	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
+	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
 	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
 	const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y));
 	StatsOut st{d_counters, d_steps, d_entry};
