@@ -427,6 +427,28 @@ int hmrm_render(const hmrm_scene *scene, const hmrm_camera *cam, uint8_t *rgba, 
 	                     nullptr, false);
 }
 
+// Progressive refresh of the reference's frame driver (hmap.cpp:976-983): only pixels
+// p = cycle, cycle + cycle_period, ... (p = x + y*width) of the caller's framebuffer are
+// rewritten, the rest keeps what earlier frames left there.  The whole frame is rendered on
+// the device (sub-millisecond) and the selected pixels are merged on the host.
+int hmrm_render_cycle(const hmrm_scene *scene, const hmrm_camera *cam, uint8_t *rgba, size_t stride_bytes,
+                      int32_t cycle, int32_t cycle_period) {
+	if (cycle_period <= 0 || cycle < 0 || cycle >= cycle_period) return fail(HMRM_E_ARG, "need 0 <= cycle < cycle_period");
+	int rc = check_camera(cam);
+	if (rc) return rc;
+	if (!rgba) return fail(HMRM_E_ARG, "NULL argument");
+	if (stride_bytes < (size_t)cam->width * 4) return fail(HMRM_E_ARG, "stride_bytes < width*4");
+	const size_t W = (size_t)cam->width, H = (size_t)cam->height;
+	std::vector<uint8_t> full(W * H * 4);
+	rc = hmrm_render(scene, cam, full.data(), W * 4);
+	if (rc != HMRM_OK && rc != HMRM_E_NOTERM) return rc;
+	for (size_t p = (size_t)cycle; p < W * H; p += (size_t)cycle_period) {
+		const size_t x = p % W, y = p / W; // hmap.cpp:982-983
+		memcpy(rgba + y * stride_bytes + x * 4, &full[p * 4], 4);
+	}
+	return rc;
+}
+
 int hmrm_render_stats(const hmrm_scene *scene, const hmrm_camera *cam, uint8_t *rgba,
                       size_t stride_bytes, hmrm_stats *stats, uint32_t *steps_per_pixel, double *entry_d) {
 	return render_common(const_cast<hmrm_scene *>(scene), cam, rgba, stride_bytes, stats,

@@ -99,6 +99,7 @@ def _load():
         "hmrm_scene_destroy": (None, [vp]),
         "hmrm_scene_read_heights": (C.c_int, [vp, vp]),
         "hmrm_render": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t]),
+        "hmrm_render_cycle": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, i32, i32]),
         "hmrm_render_rows_device": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, i32, i32, i32, i32, i32, vp]),
         "hmrm_band_local_rows": (i32, [i32, i32, i32, i32]),
         "hmrm_render_stats": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(Stats), vp, vp]),
@@ -216,6 +217,11 @@ class Scene:
         fb = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
         _check(lib.hmrm_render(self._h, C.byref(cam), _ptr(fb), cam.width * 4))
         return fb
+
+    def render_cycle(self, cam: Camera, framebuf: np.ndarray, cycle: int, cycle_period: int):
+        """Progressive refresh (hmap.cpp:976-983): rewrites pixels p = cycle (mod cycle_period) in place."""
+        assert framebuf.dtype == np.uint8 and framebuf.shape == (cam.height, cam.width, 4) and framebuf.flags.c_contiguous
+        _check(lib.hmrm_render_cycle(self._h, C.byref(cam), _ptr(framebuf), cam.width * 4, cycle, cycle_period))
 
     def render_stats(self, cam: Camera, per_pixel=False, allow_capped=False):
         fb = np.empty((cam.height, cam.width, 4), dtype=np.uint8)

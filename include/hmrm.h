@@ -118,6 +118,14 @@ int  hmrm_scene_read_heights(const hmrm_scene *scene, double *out);
 int hmrm_render(const hmrm_scene *scene, const hmrm_camera *cam,
                 uint8_t *rgba, size_t stride_bytes);
 
+/* The reference's progressive frame driver (hmap.cpp:976-983, `cycle n` key, default 47):
+ * rewrites only pixels p = cycle, cycle + cycle_period, ... (p = x + y*width) of `rgba`
+ * and leaves the others as they are; cycle_period consecutive calls with cycle = 0 ..
+ * cycle_period-1 and a static camera give the full frame.  (The reference advances
+ * `cycle = (cycle + 1) % cycle_period` before each frame, hmap.cpp:976.) */
+int hmrm_render_cycle(const hmrm_scene *scene, const hmrm_camera *cam,
+                      uint8_t *rgba, size_t stride_bytes, int32_t cycle, int32_t cycle_period);
+
 /* Same pass restricted to rows [row_begin,row_end) of the frame, written to a
  * DEVICE buffer that holds only those rows (row row_begin at d_rgba), enqueued
  * on `hip_stream` (a hipStream_t, NULL = default stream) without a host sync.

@@ -443,3 +443,25 @@ def test_random_cameras_and_parameters_fuzz(gpu, oracle):
     finally:
         del os.environ["HMRM_STEP_CAP"]
     assert checked == 48 and leaped > 0
+
+
+def test_progressive_cycle_refresh(gpu, oracle):
+    """`cycle n` (hmap.cpp:976-983): each call rewrites pixels p = cycle (mod n); n calls give the frame."""
+    rgb, cmap = scenes.small_maps(64, 64, 55)
+    params = gpu.SceneParams.make(0.0, 8.0, grid_width=1.0)
+    cam = gpu.Camera.make(width=53, height=37, projection=1, hfov=gpu.degrees_to_rads(90), hang=gpu.degrees_to_rads(-45),
+                          vang=gpu.degrees_to_rads(118), pos=(-10.0, 10.0, 24.0), step_dist=0.5, bg=(12, 34, 56))
+    scene = gpu.Scene(rgb, cmap, params)
+    full = scene.render(cam)
+    period = 47  # the reference's default cycle_period (hmap.cpp:71)
+    fb = np.full_like(full, 7)
+    scene.render_cycle(cam, fb, 3, period)
+    p = np.arange(cam.width * cam.height).reshape(cam.height, cam.width)
+    sel = (p % period) == 3
+    assert np.array_equal(fb[sel], full[sel]) and (fb[~sel] == 7).all()
+    for c in range(period):
+        scene.render_cycle(cam, fb, c, period)
+    assert np.array_equal(fb, full)
+    with pytest.raises(gpu.HmrmError):
+        scene.render_cycle(cam, fb, 47, 47)
+    scene.close()
