@@ -127,7 +127,7 @@ bool decode_bmp(const uint8_t *bytes, size_t len, int req_comp, Image *img, std:
 	std::vector<uint8_t> out((size_t)img_x * img_y * target);
 	size_t z = 0;
 	if (bpp < 16) {
-		if (psize == 0 || psize > 256) return fail("invalid");
+		if (psize <= 0 || psize > 256) return fail("invalid"); // (stb reads an uninitialised palette for psize < 0)
 		uint8_t pal[256][4];
 		for (int i = 0; i < psize; ++i) {
 			pal[i][2] = (uint8_t)s.get8(); pal[i][1] = (uint8_t)s.get8(); pal[i][0] = (uint8_t)s.get8();
@@ -271,6 +271,7 @@ bool decode_tga(const uint8_t *bytes, size_t len, int req_comp, Image *img, std:
 	const int comp = indexed ? tga_components(pal_bits, false, &rgb16) : tga_components(bpp, image_type == 3, &rgb16);
 	if (!comp) return fail("bad format");
 	if (W <= 0 || H <= 0) return fail("bad format");
+	if ((int64_t)W * H * comp > ((int64_t)1 << 30)) return fail("too large");
 	std::vector<uint8_t> data((size_t)W * H * comp, 0);
 	s.skip(id_len);
 	auto read_rgb16 = [&](uint8_t *out) {
@@ -323,7 +324,7 @@ bool decode_tga(const uint8_t *bytes, size_t len, int req_comp, Image *img, std:
 				read_next = false;
 			}
 			for (int j = 0; j < comp; ++j) data[i * comp + j] = raw[j];
-			--rle_count;
+			if (rle) --rle_count;
 		}
 		if (inverted) {
 			const size_t row = (size_t)W * comp;

@@ -290,7 +290,7 @@ bool unfilter(const uint8_t *raw, size_t raw_len, size_t row_bytes, uint32_t row
 void expand_samples(const std::vector<uint8_t> &packed, size_t row_bytes, uint32_t w, uint32_t h,
                     int n, int depth, bool scale_grey, std::vector<uint16_t> *out) {
 	static const int scale_tab[9] = {0, 0xff, 0x55, 0, 0x11, 0, 0, 0, 0x01};
-	const int scale = scale_grey ? scale_tab[depth] : 1;
+	const int scale = (scale_grey && depth <= 8) ? scale_tab[depth] : 1; // 16-bit grey is not scaled
 	out->resize((size_t)w * h * n);
 	for (uint32_t y = 0; y < h; ++y) {
 		const uint8_t *row = packed.data() + row_bytes * (size_t)y;

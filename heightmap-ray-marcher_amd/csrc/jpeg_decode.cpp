@@ -113,7 +113,8 @@ struct Decoder {
 					return;
 				}
 			}
-			code_buffer |= b << (24 - code_bits);
+			const int sh = 24 - code_bits; // > 31 only after a corrupt stream drove code_bits negative
+			if (sh < 32) code_buffer |= b << sh;
 			code_bits += 8;
 		} while (code_bits <= 24);
 	}
@@ -121,7 +122,7 @@ struct Decoder {
 		if (code_bits < 16) grow();
 		const uint32_t temp = code_buffer >> 16;
 		int k;
-		for (k = 1;; ++k)
+		for (k = 1; k < 17; ++k) // (a table that was never defined has maxcode all zero: k runs to 17)
 			if (temp < h.maxcode[k]) break;
 		if (k == 17) { code_bits -= 16; return -1; }
 		if (k > code_bits) return -1;
@@ -131,7 +132,7 @@ struct Decoder {
 		code_buffer <<= k;
 		return h.values[c];
 	}
-	static uint32_t rotl(uint32_t v, int n) { return n ? (v << n) | (v >> (32 - n)) : v; }
+	static uint32_t rotl(uint32_t v, int n) { n &= 31; return n ? (v << n) | (v >> (32 - n)) : v; }
 	int extend_receive(int n) { // JPEG RECEIVE + EXTEND
 		if (code_bits < n) grow();
 		const int sgn = (int)(code_buffer >> 31);

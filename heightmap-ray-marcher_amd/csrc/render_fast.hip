@@ -128,8 +128,11 @@ __device__ __forceinline__ bool axis_landing_ok(const Axis &a, double pn) {
 
 } // namespace
 
+#ifndef HMRM_MIN_WAVES
+#define HMRM_MIN_WAVES 1
+#endif
 template <int PROJ, bool STATS, int GWM, bool LEAP>
-__global__ __launch_bounds__(256) void k_render_fast(const DevFrame f, const RowMap rows,
+__global__ __launch_bounds__(256, HMRM_MIN_WAVES) void k_render_fast(const DevFrame f, const RowMap rows,
                                                      const double *__restrict__ thr,
                                                      const uint32_t *__restrict__ cmap,
                                                      uint32_t *__restrict__ out, int64_t out_stride_px,
