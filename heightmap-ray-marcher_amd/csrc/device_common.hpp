@@ -139,12 +139,20 @@ __device__ __forceinline__ uint32_t shade_hit(const DevFrame &f, uint32_t texel)
 }
 
 // Which pixel a lane owns.  A wave covers kWaveW x kWaveH pixels (kWaveW * kWaveH = 64), a
-// 256-thread workgroup a 2 x 2 arrangement of waves.
+// workgroup a kWavesX x kWavesY arrangement of waves (default 2 x 2 = 256 threads).
 #ifndef HMRM_WAVE_W
 #define HMRM_WAVE_W 8
 #endif
+#ifndef HMRM_WAVES_X
+#define HMRM_WAVES_X 1
+#endif
+#ifndef HMRM_WAVES_Y
+#define HMRM_WAVES_Y 2
+#endif
 constexpr int kWaveW = HMRM_WAVE_W, kWaveH = 64 / HMRM_WAVE_W;
-constexpr int kTileW = 2 * kWaveW, kTileH = 2 * kWaveH;
+constexpr int kWavesX = HMRM_WAVES_X, kWavesY = HMRM_WAVES_Y;          // waves per workgroup
+constexpr int kBlockThreads = 64 * kWavesX * kWavesY;
+constexpr int kTileW = kWavesX * kWaveW, kTileH = kWavesY * kWaveH;
 struct PixelId {
 	int px, py, lrow;
 	bool live;
@@ -154,8 +162,8 @@ __device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	PixelId p;
-	p.px = tile_x * kTileW + (wave & 1) * kWaveW + (lane % kWaveW);
-	p.lrow = tile_y * kTileH + (wave >> 1) * kWaveH + (lane / kWaveW);
+	p.px = tile_x * kTileW + (wave % kWavesX) * kWaveW + (lane % kWaveW);
+	p.lrow = tile_y * kTileH + (wave / kWavesX) * kWaveH + (lane / kWaveW);
 	if (rows.band_rows > 0) {
 		const int band = p.lrow / rows.band_rows, within = p.lrow - band * rows.band_rows;
 		p.py = (rows.band_index + band * rows.band_count) * rows.band_rows + within;

@@ -76,28 +76,17 @@ __global__ __launch_bounds__(256) void k_prepare_heights(const uint8_t *__restri
 }
 
 template <int PROJ, bool STATS>
-__global__ __launch_bounds__(256) void k_render(const DevFrame f, const RowMap rows,
+__global__ __launch_bounds__(kBlockThreads) void k_render(const DevFrame f, const RowMap rows,
                                                 const double *__restrict__ thr,
                                                 const uint32_t *__restrict__ cmap,
                                                 uint32_t *__restrict__ out, int64_t out_stride_px,
                                                 int tiles_x, StatsOut st) {
-	// 16x16 pixel tile per workgroup, one 8x8 sub-tile per wave: neighbouring rays
-	// walk neighbouring ground tracks, so a wave's height loads share cache lines
-	// and its lanes leave the loop at similar times.
-	const int tile = blockIdx.x;
-	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-	const int lrow = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-
-	int py; // global framebuffer row of this lane
-	if (rows.band_rows > 0) {
-		const int band = lrow / rows.band_rows, within = lrow - band * rows.band_rows;
-		py = (rows.band_index + band * rows.band_count) * rows.band_rows + within;
-	} else {
-		py = rows.row_begin + lrow;
-	}
-	const bool live = px < f.screen_w && lrow < rows.local_rows && py < f.screen_h;
+	// one small pixel tile per wave (device_common.hpp): neighbouring rays walk neighbouring
+	// ground tracks, so a wave's height loads share cache lines and its lanes leave the loop
+	// at similar times.
+	const PixelId pid = pixel_of_lane(f, rows, tiles_x);
+	const int px = pid.px, py = pid.py, lrow = pid.lrow;
+	const bool live = pid.live;
 
 	unsigned long long my_steps = 0;
 	uint32_t my_hit = 0, my_cap = 0;
@@ -177,21 +166,7 @@ __global__ __launch_bounds__(256) void k_render(const DevFrame f, const RowMap r
 			    my_steps > 0xffffffffull ? 0xffffffffu : (uint32_t)my_steps;
 	}
 
-	if (STATS) {
-		unsigned long long s = my_steps, h = my_hit, c = my_cap;
-		for (int off = 32; off > 0; off >>= 1) {
-			s += __shfl_xor(s, off);
-			h += __shfl_xor(h, off);
-			c += __shfl_xor(c, off);
-		}
-		if (lane == 0) {
-			if (s) atomicAdd(&st.counters[0], s);
-			if (h) atomicAdd(&st.counters[1], h);
-			if (c) atomicAdd(&st.counters[2], c);
-		}
-	} else if (my_cap) {
-		atomicAdd(&st.counters[2], 1ull);
-	}
+	publish_counters<STATS>(st, my_steps, my_hit, my_cap);
 }
 
 // Per-ray parity hook: GetRay + distance() of one pixel -> out[0..2] pos, [3..5] dir, [6] d.
@@ -243,7 +218,7 @@ static hipError_t launch_render_t(const DevFrame &f, const RowMap &rows, const d
 	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
 	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
 	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
-	const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y)), block(256);
+	const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y)), block(kBlockThreads);
 	switch (f.projection) {
 	case 1:
 		hipLaunchKernelGGL((k_render<1, STATS>), grid, block, 0, stream, f, rows, d_thr, d_cmap, d_out,

@@ -132,7 +132,7 @@ __device__ __forceinline__ bool axis_landing_ok(const Axis &a, double pn) {
 #define HMRM_MIN_WAVES 1
 #endif
 template <int PROJ, bool STATS, int GWM, bool LEAP>
-__global__ __launch_bounds__(256, HMRM_MIN_WAVES) void k_render_fast(const DevFrame f, const RowMap rows,
+__global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(const DevFrame f, const RowMap rows,
                                                      const double *__restrict__ thr,
                                                      const uint32_t *__restrict__ cmap,
                                                      uint32_t *__restrict__ out, int64_t out_stride_px,
@@ -434,7 +434,7 @@ template <int PROJ, bool STATS, int GWM, bool LEAP>
 static void launch_one(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
                        uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid, int tiles_x,
                        hipStream_t stream) {
-	hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP>), grid, dim3(256), 0, stream, f, rows, d_thr,
+	hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP>), grid, dim3(kBlockThreads), 0, stream, f, rows, d_thr,
 	                   d_cmap, d_out, out_stride_px, tiles_x, st);
 }
 
