@@ -50,21 +50,19 @@ __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned
 __device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)(unsigned long long)__double_as_longlong(v); }
 __device__ __forceinline__ double f64_from_hi(uint32_t hi) { return __longlong_as_double((long long)((unsigned long long)hi << 32)); }
 
-// Cell coordinate q with trunc(q) == trunc(v / grid_width) and identical range
-// predicates (q > -1, q < N); v is x - c0.x or -(y - c0.y) with c0.x = c0.y = 0.0
-// (hmap.cpp:968: v - 0.0 == v for every v, so the subtraction is elided).
-//   GWM 0: grid_width == 1.0          -> q = v
-//   GWM 1: grid_width = 2^k           -> q = v * 2^-k          (exact reciprocal)
-//   GWM 2: any grid_width             -> q' = v * fl(1/gw) differs from v/gw by < 2^-50
-//          relative; unless q' is within 2^-20 of an integer (or huge / NaN) both
-//          truncate alike and compare alike with integers; otherwise divide for real.
+// Cell coordinate q with trunc(q) == trunc(v / grid_width); v is x - c0.x or -(y - c0.y) with
+// c0.x = c0.y = 0.0 (hmap.cpp:968: v - 0.0 == v for every v, so the subtraction is elided).
+//   GWM 0: grid_width == 1.0   -> q = v
+//   GWM 1: grid_width = 2^k    -> q = v * 2^-k                 (exact reciprocal)
+//   GWM 2: any grid_width      -> q' = v * fl(1/gw), which differs from the correctly rounded
+//          v/gw by < 2^-50 relative.  Unless q' lies within 2^-20 of an integer both truncate to
+//          the same cell (for |q'| >= 2^28 both are far outside any map, whatever they truncate
+//          to); `near` collects that rare case and the caller then divides for real.
 template <int GWM>
-__device__ __forceinline__ double cell_coord(double v, const DevFrame &f) {
+__device__ __forceinline__ double cell_coord_fast(double v, const DevFrame &f, bool &near) {
 	if (GWM == 0) return v;
-	if (GWM == 1) return v * f.inv_grid_width;
-	double q = v * f.inv_grid_width;
-	const double fr = q - __builtin_rint(q);
-	if (!(__builtin_fabs(fr) > 0x1p-20) || !(__builtin_fabs(q) < 0x1p28)) q = v / f.grid_width;
+	const double q = v * f.inv_grid_width;
+	if (GWM == 2) near = near || !(__builtin_fabs(__builtin_amdgcn_fract(q) - 0.5) < 0.5 - 0x1p-20);
 	return q;
 }
 
@@ -196,7 +194,9 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						if ((hi32(x) >> 20) != ax.key) axis_refresh(ax, x, sx);
 						if ((hi32(y) >> 20) != ay.key) axis_refresh(ay, y, sy);
 						if ((hi32(z) >> 20) != az.key) axis_refresh(az, z, sz);
-						const double qx = cell_coord<GWM>(x, f), qy = cell_coord<GWM>(-y, f);
+						bool near0 = false;
+						double qx = cell_coord_fast<GWM>(x, f, near0), qy = cell_coord_fast<GWM>(-y, f, near0);
+						if (GWM == 2 && near0) { qx = x / f.grid_width; qy = -y / f.grid_width; }
 						const int gx = cvt_i32_sat(qx), gy = cvt_i32_sat(qy);
 						const bool inb0 = (unsigned)gx < wlim && (unsigned)gy < hlim;
 						const bool exact = ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
@@ -232,7 +232,9 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						// landing point and its exact verification
 						const double nn = (double)n;
 						const double xn = x + nn * ax.delta, yn = y + nn * ay.delta, zn = z + nn * az.delta;
-						const double qxn = cell_coord<GWM>(xn, f), qyn = cell_coord<GWM>(-yn, f);
+						bool nearn = false;
+						double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
+						if (GWM == 2 && nearn) { qxn = xn / f.grid_width; qyn = -yn / f.grid_width; }
 						const int gxn = cvt_i32_sat(qxn), gyn = cvt_i32_sat(qyn);
 						const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim;
 						const bool ok = can && inbn && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
@@ -288,9 +290,23 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 					Y[j] = Y[j - 1] + sy;
 					Z[j] = Z[j - 1] + sz;
 				}
+				double QX[kGroup], QY[kGroup];
+				bool near = false;
 #pragma unroll
 				for (int j = 0; j < kGroup; ++j) {
-					const double qx = cell_coord<GWM>(X[j], f), qy = cell_coord<GWM>(-Y[j], f);
+					QX[j] = cell_coord_fast<GWM>(X[j], f, near);
+					QY[j] = cell_coord_fast<GWM>(-Y[j], f, near);
+				}
+				if (GWM == 2 && near) { // some position sits on a cell boundary to within 2^-20: divide
+#pragma unroll
+					for (int j = 0; j < kGroup; ++j) {
+						QX[j] = X[j] / f.grid_width;
+						QY[j] = -Y[j] / f.grid_width;
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < kGroup; ++j) {
+					const double qx = QX[j], qy = QY[j];
 					const int gx = cvt_i32_sat(qx), gy = cvt_i32_sat(qy); // hmap.cpp:1001-1004
 					inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;      // hmap.cpp:1006-1011
 					cell[j] = inb[j] ? gy * f.map_w + gx : 0;
