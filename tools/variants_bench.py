@@ -10,6 +10,7 @@ for name in sys.argv[1:] or ["C3"]:
     rgb, cmap = hmrm.synth.synth_maps(wl.map_size)
     scene = hmrm.Scene(rgb, cmap, wl.scene_params())
     cam = wl.camera()
+    os.environ["HMRM_KERNEL"] = "leap"
     _, st, _, _ = scene.render_stats(cam)
     print(f"{name} diag: attempts {st.leap_attempts} leaps {st.leaps} groups {st.groups} leaped_steps {st.leaped_steps} "
           f"of {st.steps}; entering rays ~{st.hits}+; per hit-ray: attempts {st.leap_attempts/max(st.hits,1):.1f} "
