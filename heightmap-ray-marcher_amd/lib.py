@@ -9,7 +9,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from dataclasses import dataclass, field
 
 import numpy as np
 
@@ -197,7 +196,7 @@ class Scene:
         return s
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (lib is None during interpreter shutdown)
             lib.hmrm_scene_destroy(self._h)
             self._h = None
 
@@ -292,7 +291,7 @@ class Config:
         self._h = C.c_void_p(lib.hmrm_config_create())
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.hmrm_config_destroy(self._h)
             self._h = None
 
