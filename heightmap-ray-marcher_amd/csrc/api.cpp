@@ -65,6 +65,9 @@ struct hmrm_scene {
 	uint32_t *d_cmap = nullptr; // W*H    colormap_buf as packed RGBA (hmap.cpp:59)
 	double *d_thr = nullptr;    // W*H    heightmap_buf[i] + min_height
 	double thr_max = 0.0;
+	double thr_max_bil = 0.0; // whole-map bound of the interpolated thresholds (bilinear mode)
+	bool bil_valid = false;
+	float *d_mipbuf_bil = nullptr; // the same over the 3x3-dilated table (bilinear quality mode)
 	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/16/64/256-cell windows every 2/8/32/128 cells
 	int32_t mip_w[4] = {0, 0, 0, 0}, mip_h[4] = {0, 0, 0, 0}, mip_off[4] = {0, 0, 0, 0};
 	hipStream_t stream = nullptr;
@@ -101,7 +104,7 @@ hipError_t launch_variant(const hmrm::DevFrame &f, const hmrm::RowMap &rows, con
                           uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry,
                           bool stats, hipStream_t stream) {
 	const char *k = getenv("HMRM_KERNEL");
-	if (k && strcmp(k, "simple") == 0)
+	if (k && strcmp(k, "simple") == 0 && f.sampling == 0) // (the literal loop only knows the reference's sampling)
 		return hmrm::launch_render(f, rows, s->d_thr, s->d_cmap, d_out, out_stride_px, s->d_counters, d_steps,
 		                           d_entry, stats, stream);
 	const bool leap = !(k && strcmp(k, "group") == 0);
@@ -154,6 +157,8 @@ int check_camera(const hmrm_camera *cam) {
 	return HMRM_OK;
 }
 
+int ensure_bilinear_pyramid(hmrm_scene *s);
+
 // Host set-up for one frame: fills `f` and, for spherical, enqueues the table upload.
 // The result is a pure function of (camera, scene params, map size), so the last one is
 // kept: a static camera re-renders without redoing the libm calls or the table upload
@@ -194,6 +199,7 @@ int prepare_frame_uncached(hmrm_scene *s, const hmrm_camera *cam, hipStream_t st
 	hc.bg_r = cam->bg_r;
 	hc.bg_g = cam->bg_g;
 	hc.bg_b = cam->bg_b;
+	hc.sampling = cam->sampling;
 	hc.hfov = cam->hfov;
 	hc.hang = cam->hang;
 	hc.vang = cam->vang;
@@ -222,7 +228,11 @@ int prepare_frame_uncached(hmrm_scene *s, const hmrm_camera *cam, hipStream_t st
 		f->row_sin_va = s->d_tables + 2 * W;
 		f->row_cos_va = s->d_tables + 2 * W + H;
 	}
-	f->thr_max = s->thr_max;
+	if (cam->sampling == HMRM_BILINEAR) {
+		const int rc = ensure_bilinear_pyramid(s);
+		if (rc != HMRM_OK) return rc;
+	}
+	f->thr_max = cam->sampling == HMRM_BILINEAR ? s->thr_max_bil : s->thr_max;
 	f->step_cap = default_step_cap();
 	// diagnostic: HMRM_DIAG_ITERS=1 makes the instrumented kernel report (attempts<<16 | groups)
 	// per pixel instead of the step count (tools/ only)
@@ -232,8 +242,40 @@ int prepare_frame_uncached(hmrm_scene *s, const hmrm_camera *cam, hipStream_t st
 	}
 	for (int l = 0; l < hmrm::kMipLevels; ++l) {
 		f->mipbuf = s->d_mipbuf;
+		f->mipbuf_bil = s->d_mipbuf_bil;
 		f->mip_off[l] = s->mip_off[l];
 	}
+	return HMRM_OK;
+}
+
+// Bilinear quality mode only: the second pyramid, over the 3x3-dilated (and margin-padded)
+// table, built the first time a bilinear frame is asked for after a height update.
+int ensure_bilinear_pyramid(hmrm_scene *s) {
+	if (s->bil_valid) return HMRM_OK;
+	const int64_t n = (int64_t)s->map_w * s->map_h;
+	double *tmp = nullptr;
+	HIP_TRY(hipMalloc((void **)&tmp, (size_t)n * sizeof(double)));
+	hipError_t e = hmrm::launch_dilate3x3(s->d_thr, s->map_w, s->map_h, tmp, s->stream);
+	if (e == hipSuccess)
+		e = hmrm::launch_build_mip0(tmp, s->map_w, s->map_h, s->d_mipbuf_bil + s->mip_off[0], s->mip_w[0],
+		                            s->mip_h[0], s->stream);
+	for (int l = 1; l < hmrm::kMipLevels && e == hipSuccess; ++l)
+		e = hmrm::launch_build_mip_up(s->d_mipbuf_bil + s->mip_off[l - 1], s->mip_w[l - 1], s->mip_h[l - 1],
+		                              s->d_mipbuf_bil + s->mip_off[l], s->mip_w[l], s->mip_h[l], s->stream);
+	// whole-map bound = max over the coarsest level (its windows cover every cell)
+	const int top = hmrm::kMipLevels - 1;
+	std::vector<float> coarse((size_t)s->mip_w[top] * s->mip_h[top]);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(coarse.data(), s->d_mipbuf_bil + s->mip_off[top], coarse.size() * sizeof(float),
+		                   hipMemcpyDeviceToHost, s->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+	(void)hipFree(tmp);
+	if (e != hipSuccess) return fail(HMRM_E_DEVICE, std::string("bilinear pyramid: ") + hipGetErrorString(e));
+	double m = -__builtin_huge_val();
+	for (float v : coarse)
+		if ((double)v > m) m = (double)v;
+	s->thr_max_bil = m;
+	s->bil_valid = true;
 	return HMRM_OK;
 }
 
@@ -249,6 +291,8 @@ int run_update_heights(hmrm_scene *s) {
 	for (int l = 1; l < hmrm::kMipLevels; ++l)
 		HIP_TRY(hmrm::launch_build_mip_up(s->d_mipbuf + s->mip_off[l - 1], s->mip_w[l - 1], s->mip_h[l - 1],
 		                                  s->d_mipbuf + s->mip_off[l], s->mip_w[l], s->mip_h[l], s->stream));
+	s->bil_valid = false; // rebuilt by the next bilinear frame
+	s->cache_valid = false;
 	unsigned long long key = 0;
 	HIP_TRY(hipMemcpyAsync(&key, s->d_counters + 3, sizeof key, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -308,6 +352,7 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 			const int last = hmrm::kMipLevels - 1;
 			const size_t total = (size_t)s->mip_off[last] + (size_t)s->mip_w[last] * s->mip_h[last];
 			HIP_TRY(hipMalloc((void **)&s->d_mipbuf, total * sizeof(float)));
+			HIP_TRY(hipMalloc((void **)&s->d_mipbuf_bil, total * sizeof(float)));
 		}
 		HIP_TRY(hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long)));
 		HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->stream));
@@ -341,6 +386,7 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (s->d_cmap) (void)hipFree(s->d_cmap);
 	if (s->d_thr) (void)hipFree(s->d_thr);
 	if (s->d_mipbuf) (void)hipFree(s->d_mipbuf);
+	if (s->d_mipbuf_bil) (void)hipFree(s->d_mipbuf_bil);
 	if (s->d_counters) (void)hipFree(s->d_counters);
 	if (s->d_frame) (void)hipFree(s->d_frame);
 	if (s->d_tables) (void)hipFree(s->d_tables);
@@ -571,6 +617,7 @@ void hmrm_config_get_camera(const hmrm_config *c, hmrm_camera *out) {
 	out->bg_r = g.bg_r;
 	out->bg_g = g.bg_g;
 	out->bg_b = g.bg_b;
+	out->sampling = (uint8_t)g.sampling;
 	out->hfov = g.hfov;
 	out->hang = g.hang;
 	out->vang = g.vang;
@@ -720,7 +767,7 @@ int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params, in
 	if (cam->projection == HMRM_SPHERICAL && !tables) return fail(HMRM_E_ARG, "tables required for spherical");
 	hmrm::HostCamera hc{};
 	hc.width = cam->width; hc.height = cam->height; hc.projection = cam->projection;
-	hc.bg_r = cam->bg_r; hc.bg_g = cam->bg_g; hc.bg_b = cam->bg_b;
+	hc.bg_r = cam->bg_r; hc.bg_g = cam->bg_g; hc.bg_b = cam->bg_b; hc.sampling = cam->sampling;
 	hc.hfov = cam->hfov; hc.hang = cam->hang; hc.vang = cam->vang;
 	hc.pos[0] = cam->pos[0]; hc.pos[1] = cam->pos[1]; hc.pos[2] = cam->pos[2];
 	hc.ortho_width = cam->ortho_width; hc.step_dist = cam->step_dist;

@@ -63,6 +63,7 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min
 	f->bg[1] = cam.bg_g;
 	f->bg[2] = cam.bg_b;
 	f->bg[3] = 255;
+	f->sampling = cam.sampling;
 
 	const Vec3 pos{cam.pos[0], cam.pos[1], cam.pos[2]};
 	store(f->cam, pos);

@@ -9,6 +9,7 @@
 // keys at run time, :851-868, and only ever writes PNG):
 //   projection perspective|spherical|orthographic   (or 1|2|3)
 //   output <path>                                   (.png or .ppm)
+//   record orbit|off, sampling nearest|bilinear
 #include "config.hpp"
 
 #include <cmath>
@@ -189,6 +190,13 @@ bool Config::consume(std::istream &input, std::string *fatal) {
 		} else if (next == "output") { // additive
 			input >> output_path;
 			log << "output " << output_path << "\n";
+		} else if (next == "sampling") { // additive: quality mode, hmap.cpp always samples the nearest cell
+			std::string v;
+			input >> v;
+			if (v == "nearest") sampling = 0;
+			else if (v == "bilinear") sampling = 1;
+			else warn << "WARNING: Unknown sampling: " << v << "\n";
+			log << "sampling " << (sampling == 1 ? "bilinear" : "nearest") << "\n";
 		} else if (next == "record") { // additive: programmatic animation (hmap.cpp:907-926 is a stub)
 			std::string v;
 			input >> v;

@@ -34,6 +34,8 @@ struct Config {
 	std::string output_path;
 	// additive: `record orbit` renders recording_frame_count frames of an orbit sweep
 	int record_mode = 0;
+	// additive: `sampling nearest|bilinear` (nearest = the reference's truncating lookup)
+	int sampling = 0;
 
 	bool heightmap_dirty = false; // should_update_heightmap, sticky until taken
 	std::ostringstream log;       // what the reference prints to stdout

@@ -44,9 +44,10 @@ struct DevFrame {
 	// placed every S/2 cells; floats rounded up.  All levels live in one buffer: level l starts
 	// at mip_off[l] and has ceil(map_w / (S/2)) windows per row.
 	const float *mipbuf;
+	const float *mipbuf_bil;     // the same pyramid over the 3x3-dilated table (bilinear quality mode)
 	int32_t mip_off[4];
 	int32_t diag_mode;           // tools only: what the instrumented kernel writes per pixel
-	int32_t pad2_;
+	int32_t sampling;            // 0 nearest cell (the reference), 1 bilinear quality mode
 };
 
 constexpr int kMipLevels = 4;
@@ -65,7 +66,7 @@ struct RowMap {
 // projection == 2.  Returns false on invalid arguments.
 struct HostCamera {
 	int32_t width, height, projection;
-	uint8_t bg_r, bg_g, bg_b;
+	uint8_t bg_r, bg_g, bg_b, sampling;
 	double hfov, hang, vang, pos[3], ortho_width, step_dist;
 };
 

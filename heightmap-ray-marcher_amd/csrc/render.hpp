@@ -29,6 +29,8 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
                               bool leap, hipStream_t stream);
+// 3x3 maximum filter of the thr table (bounds every bilinear interpolation, render_fast.hip).
+hipError_t launch_dilate3x3(const double *d_thr, int w, int h, double *d_dst, hipStream_t stream);
 // Window-maximum pyramid (see render_fast.hip): level 0 from the thr table, level l+1 from level l.
 hipError_t launch_build_mip0(const double *d_thr, int map_w, int map_h, float *d_dst, int dst_w, int dst_h,
                              hipStream_t stream);

@@ -79,6 +79,52 @@ __device__ __forceinline__ int cvt_i32_sat(double q) {
 	return r;
 }
 
+// ---- bilinear quality mode (HMRM_BILINEAR; a build-side addition, not in the reference) ----
+// Same definition, operation for operation, as oracle/hmrm_oracle.c "bilinear quality mode":
+// values sit at cell centres; u = q - 0.5, t = u - floor(u), neighbours clamp(floor(u)) and
+// clamp(floor(u) + 1); f = a + ty*(b - a), a = f00 + tx*(f10 - f00), b = f01 + tx*(f11 - f01).
+struct Bil {
+	int c00, c10, c01, c11; // the four neighbour cells (linear indices)
+	double tx, ty;
+};
+__device__ __forceinline__ Bil bil_setup(double qx, double qy, int w, int h) {
+	const double u = qx - 0.5, v = qy - 0.5;
+	const double fu = __builtin_floor(u), fv = __builtin_floor(v);
+	Bil b;
+	b.tx = u - fu;
+	b.ty = v - fv;
+	const int iu = cvt_i32_sat(fu), iv = cvt_i32_sat(fv);
+	const int i0 = min(max(iu, 0), w - 1), i1 = min(max(iu + 1, 0), w - 1);
+	const int j0 = min(max(iv, 0), h - 1), j1 = min(max(iv + 1, 0), h - 1);
+	b.c00 = j0 * w + i0; b.c10 = j0 * w + i1;
+	b.c01 = j1 * w + i0; b.c11 = j1 * w + i1;
+	return b;
+}
+__device__ __forceinline__ double bil_mix(const Bil &b, double f00, double f10, double f01, double f11) {
+	const double a = f00 + b.tx * (f10 - f00);
+	const double c = f01 + b.tx * (f11 - f01);
+	return a + b.ty * (c - a);
+}
+// Colour at a hit: R,G,B interpolated and rounded with floor(f + 0.5); the alpha-0 rule
+// (hmap.cpp:1020) keeps looking at the nearest cell.
+__device__ __forceinline__ uint32_t shade_hit_bilinear(const DevFrame &f, const uint32_t *__restrict__ cmap,
+                                                       int nearest_cell, const Bil &b) {
+	const uint32_t tn = cmap[nearest_cell];
+	if ((tn >> 24) == 0) return pack_rgba(f.bg[0], f.bg[1], f.bg[2]);
+	const uint32_t t00 = cmap[b.c00], t10 = cmap[b.c10], t01 = cmap[b.c01], t11 = cmap[b.c11];
+	uint32_t ch[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const int sh = 8 * k;
+		double v = bil_mix(b, (double)((t00 >> sh) & 255u), (double)((t10 >> sh) & 255u),
+		                   (double)((t01 >> sh) & 255u), (double)((t11 >> sh) & 255u)) + 0.5;
+		if (v < 0.0) v = 0.0;
+		else if (v > 255.0) v = 255.0;
+		ch[k] = (uint32_t)(int)__builtin_floor(v);
+	}
+	return pack_rgba(ch[0], ch[1], ch[2]);
+}
+
 // Exact-stepping state of one coordinate inside its current binade.
 struct Axis {
 	double delta;  // p_{k+1} - p_k for every p of the binade (valid iff key matches)
@@ -129,7 +175,7 @@ __device__ __forceinline__ bool axis_landing_ok(const Axis &a, double pn) {
 #ifndef HMRM_MIN_WAVES
 #define HMRM_MIN_WAVES 1
 #endif
-template <int PROJ, bool STATS, int GWM, bool LEAP>
+template <int PROJ, bool STATS, int GWM, bool LEAP, bool BILINEAR>
 __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(const DevFrame f, const RowMap rows,
                                                      const double *__restrict__ thr,
                                                      const uint32_t *__restrict__ cmap,
@@ -208,8 +254,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						iy = iy < 0 ? 0 : iy;
 						const int mw = (f.map_w + (1 << hs) - 1) >> hs; // windows per row (as built on the host)
 						const int loff = lev == 0 ? 0 : (lev == 1 ? f.mip_off[1] : (lev == 2 ? f.mip_off[2] : f.mip_off[3]));
-						const float mf = f.mipbuf[(top || !inb0) ? 0 : loff + iy * mw + ix];
-						const double m = top ? f.thr_max : (double)mf;
+						const float mf = (BILINEAR ? f.mipbuf_bil : f.mipbuf)[(top || !inb0) ? 0 : loff + iy * mw + ix];
+						const double m = top ? f.thr_max : (double)mf; // (thr_max also bounds every interpolated threshold)
 						const int wx0 = top ? 0 : ix << hs, wy0 = top ? 0 : iy << hs;
 						const int wspan_x = top ? f.map_w : 2 << hs, wspan_y = top ? f.map_h : 2 << hs;
 						const bool above = z >= m;
@@ -297,7 +343,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 					QX[j] = cell_coord_fast<GWM>(X[j], f, near);
 					QY[j] = cell_coord_fast<GWM>(-Y[j], f, near);
 				}
-				if (GWM == 2 && near) { // some position sits on a cell boundary to within 2^-20: divide
+				if (GWM == 2 && (near || BILINEAR)) { // on a cell boundary to within 2^-20 (or the exact q is needed): divide
 #pragma unroll
 					for (int j = 0; j < kGroup; ++j) {
 						QX[j] = X[j] / f.grid_width;
@@ -311,8 +357,17 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 					inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;      // hmap.cpp:1006-1011
 					cell[j] = inb[j] ? gy * f.map_w + gx : 0;
 				}
+				Bil bil[kGroup];
+				if (BILINEAR) {
 #pragma unroll
-				for (int j = 0; j < kGroup; ++j) T[j] = thr[cell[j]]; // hmap.cpp:1013-1014 (+ c0.z)
+					for (int j = 0; j < kGroup; ++j) {
+						bil[j] = bil_setup(inb[j] ? QX[j] : 0.0, inb[j] ? QY[j] : 0.0, f.map_w, f.map_h);
+						T[j] = bil_mix(bil[j], thr[bil[j].c00], thr[bil[j].c10], thr[bil[j].c01], thr[bil[j].c11]);
+					}
+				} else {
+#pragma unroll
+					for (int j = 0; j < kGroup; ++j) T[j] = thr[cell[j]]; // hmap.cpp:1013-1014 (+ c0.z)
+				}
 				if (budget >= kGroup) {
 					// in order: the first position that leaves the grid (:1006) or hits (:1016) ends the ray
 					const bool h0 = inb[0] && Z[0] < T[0], h1 = inb[1] && Z[1] < T[1];
@@ -326,7 +381,12 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 					if (STATS) my_steps += (unsigned)taken;
 					done = first < kGroup;
 					if (hit) {
-						rgba = shade_hit(f, cmap[hit_cell]);
+						if (BILINEAR) {
+							const Bil hb = s0 ? bil[0] : (s1 ? bil[1] : (s2 ? bil[2] : bil[3]));
+							rgba = shade_hit_bilinear(f, cmap, hit_cell, hb);
+						} else {
+							rgba = shade_hit(f, cmap[hit_cell]);
+						}
 						real_hit = true;
 					}
 				} else {
@@ -338,7 +398,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						--budget;
 						if (STATS) my_steps += 1;
 						if (Z[j] < T[j]) { // hmap.cpp:1016
-							rgba = shade_hit(f, cmap[cell[j]]);
+							rgba = BILINEAR ? shade_hit_bilinear(f, cmap, cell[j], bil[j]) : shade_hit(f, cmap[cell[j]]);
 							real_hit = true;
 							done = true;
 							break;
@@ -429,6 +489,33 @@ __global__ __launch_bounds__(256) void k_build_mip_up(const float *__restrict__ 
 	dst[i] = m;
 }
 
+// 3x3 maximum filter of the thr table (edges clamped, NaN ignored) plus a rounding margin:
+// every bilinear interpolation that a position inside cell c can see mixes four cells of c's
+// 3x3 neighbourhood, so in exact arithmetic it is at most their maximum m; the six roundings
+// of bil_mix can push it above m by a few ulp of the largest magnitude A involved (differences
+// reach 2A), hence the bound m + A * 2^-45.  A pyramid built from these values bounds the
+// interpolated thresholds of all positions whose cell lies in a window.
+__global__ __launch_bounds__(256) void k_dilate3x3(const double *__restrict__ thr, int w, int h,
+                                                   double *__restrict__ dst) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (int64_t)w * h) return;
+	const int x = (int)(i % w), y = (int)(i / w);
+	double m = -__builtin_huge_val(), a = 0.0;
+	for (int yy = max(y - 1, 0); yy <= min(y + 1, h - 1); ++yy)
+		for (int xx = max(x - 1, 0); xx <= min(x + 1, w - 1); ++xx) {
+			const double v = thr[(int64_t)yy * w + xx];
+			if (v > m) m = v;
+			if (__builtin_fabs(v) > a) a = __builtin_fabs(v);
+		}
+	dst[i] = m + a * 0x1p-45; // (inf stays inf; all-NaN neighbourhoods give -inf: never a hit there)
+}
+
+hipError_t launch_dilate3x3(const double *d_thr, int w, int h, double *d_dst, hipStream_t stream) {
+	const int64_t n = (int64_t)w * h;
+	hipLaunchKernelGGL(k_dilate3x3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_thr, w, h, d_dst);
+	return hipGetLastError();
+}
+
 hipError_t launch_build_mip0(const double *d_thr, int map_w, int map_h, float *d_dst, int dst_w, int dst_h,
                              hipStream_t stream) {
 	const int64_t n = (int64_t)dst_w * dst_h;
@@ -450,8 +537,12 @@ template <int PROJ, bool STATS, int GWM, bool LEAP>
 static void launch_one(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
                        uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid, int tiles_x,
                        hipStream_t stream) {
-	hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP>), grid, dim3(kBlockThreads), 0, stream, f, rows, d_thr,
-	                   d_cmap, d_out, out_stride_px, tiles_x, st);
+	if (f.sampling == 1)
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, true>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_x, st);
+	else
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, false>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_x, st);
 }
 
 template <int PROJ, bool STATS, int GWM>

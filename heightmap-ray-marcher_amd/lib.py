@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libhmrm.so")
 HMRM_OK = 0
 HMRM_E_ARG, HMRM_E_IO, HMRM_E_IMAGE, HMRM_E_CONFIG, HMRM_E_DEVICE, HMRM_E_NOTERM = -1, -2, -3, -4, -5, -6
 PERSPECTIVE, SPHERICAL, ORTHOGRAPHIC = 1, 2, 3
+NEAREST, BILINEAR = 0, 1
 _PROJ_NAMES = {"perspective": 1, "spherical": 2, "orthographic": 3}
 
 
@@ -42,13 +43,13 @@ class SceneParams(C.Structure):
 class Camera(C.Structure):
     """hmrm_camera -- angles in radians; defaults are main/hmap.cpp:31-35,68,75-85,98,107,110-112."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("projection", C.c_int32),
-                ("bg_r", C.c_uint8), ("bg_g", C.c_uint8), ("bg_b", C.c_uint8), ("pad_", C.c_uint8),
+                ("bg_r", C.c_uint8), ("bg_g", C.c_uint8), ("bg_b", C.c_uint8), ("sampling", C.c_uint8),
                 ("hfov", C.c_double), ("hang", C.c_double), ("vang", C.c_double),
                 ("pos", C.c_double * 3), ("ortho_width", C.c_double), ("step_dist", C.c_double)]
 
     @classmethod
     def make(cls, width=800, height=600, projection=PERSPECTIVE, hfov=np.pi / 2.0, hang=-np.pi / 4.0,
-             vang=np.pi / 2.0, pos=(-5.0, 5.0, 0.0), ortho_width=0.1, step_dist=0.25, bg=(0, 0, 0)):
+             vang=np.pi / 2.0, pos=(-5.0, 5.0, 0.0), ortho_width=0.1, step_dist=0.25, bg=(0, 0, 0), sampling=0):
         if isinstance(projection, str):
             projection = _PROJ_NAMES[projection]
         c = cls()
@@ -57,6 +58,7 @@ class Camera(C.Structure):
         c.hfov, c.hang, c.vang = float(hfov), float(hang), float(vang)
         c.pos[0], c.pos[1], c.pos[2] = (float(v) for v in pos)
         c.ortho_width, c.step_dist = float(ortho_width), float(step_dist)
+        c.sampling = int(sampling)
         return c
 
 

@@ -44,6 +44,17 @@ enum {
 	HMRM_ORTHOGRAPHIC = 3
 };
 
+/* Height / colour sampling.  The reference samples the nearest cell with C truncation
+ * (hmap.cpp:1001-1004,1013-1018): HMRM_NEAREST is the bit-exact drop-in.  HMRM_BILINEAR is a
+ * build-side quality mode (north_star: "bilinear height/colour sampling"), not in the reference:
+ * cell values sit at cell centres, thresholds and R,G,B are interpolated bilinearly in fp64
+ * (definition: oracle/hmrm_oracle.c "bilinear quality mode"); additive config key
+ * `sampling nearest|bilinear`. */
+enum {
+	HMRM_NEAREST  = 0,
+	HMRM_BILINEAR = 1
+};
+
 /* The globals UpdateHeightmap() and the box corners read:
  * main/hmap.cpp:38-47 (min/max_height, lum_*), :65 (grid_width). */
 typedef struct hmrm_scene_params {
@@ -63,7 +74,8 @@ typedef struct hmrm_camera {
 	int32_t  width;        /* screen_width  */
 	int32_t  height;       /* screen_height */
 	int32_t  projection;   /* HMRM_PERSPECTIVE | HMRM_SPHERICAL | HMRM_ORTHOGRAPHIC */
-	uint8_t  bg_r, bg_g, bg_b, pad_;
+	uint8_t  bg_r, bg_g, bg_b;
+	uint8_t  sampling;     /* HMRM_NEAREST (0, the reference) | HMRM_BILINEAR (1, quality mode) */
 	double   hfov;
 	double   hang;
 	double   vang;
@@ -195,7 +207,7 @@ int hmrm_record_orbit(const hmrm_scene *scene, const hmrm_camera *base, double c
  * every option to `echo_fd`-style sinks: echo text is appended to an internal
  * log retrievable with hmrm_config_log().  Additive keys (not in the reference,
  * named by north_star): `projection perspective|spherical|orthographic|1|2|3`,
- * `output <path.png|.ppm>`, `record orbit|off`.  Unknown key -> "WARNING: Unknown identifier: k". */
+ * `output <path.png|.ppm>`, `record orbit|off`, `sampling nearest|bilinear`.  Unknown key -> "WARNING: Unknown identifier: k". */
 hmrm_config *hmrm_config_create(void);
 void         hmrm_config_destroy(hmrm_config *cfg);
 /* Consume a whole stream; loads heightmap/colormap images when those keys

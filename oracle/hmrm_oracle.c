@@ -75,7 +75,8 @@ typedef struct {
 	double min_height, max_height;         /* :38-39 */
 	double grid_width, step_dist, ortho_width; /* :65,68,98 */
 	uint8_t bg_r, bg_g, bg_b;              /* :110-112 */
-	uint8_t pad_;
+	uint8_t sampling;   /* 0 = nearest cell (the reference, :1001-1018); 1 = bilinear quality mode
+	                       (NOT in the reference: a build-side addition, defined below) */
 	int64_t step_cap;   /* oracle-only guard: the reference loop is unbounded (:1000) */
 } oracle_cfg;
 
@@ -232,6 +233,39 @@ static void frame_setup(const oracle_cfg *c, plane_t *pl, v3 *c0, v3 *c1) {
 	c1->z = c->max_height;
 }
 
+/* ---- bilinear quality mode (build-side addition, no counterpart in the reference) ----------
+ * The reference samples the nearest cell.  north_star asks for bilinear height / colour
+ * sampling as an option; it is DEFINED here (and implemented identically on the GPU):
+ *   cell (i,j) carries its value at its centre (i+0.5, j+0.5) in cell units;
+ *   at cell coordinates (qx,qy):  u = qx-0.5, v = qy-0.5, tx = u-floor(u), ty = v-floor(v),
+ *   neighbours i0 = clamp(floor(u)), i1 = clamp(floor(u)+1) (same for j), and
+ *   f = a + ty*(b - a),  a = f00 + tx*(f10 - f00),  b = f01 + tx*(f11 - f01)   (fp64, no FMA).
+ * Heights interpolate the thresholds heightmap_buf + c0.z; a ray hits when z < f.  Colours
+ * interpolate each of R,G,B and round with floor(f + 0.5); the alpha-0 rule (hmap.cpp:1020)
+ * keeps looking at the nearest cell.  Range test, stepping and everything else as the reference. */
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+typedef struct { int i0, i1, j0, j1; double tx, ty; } bil_t;
+
+static bil_t bil_setup(double qx, double qy, int w, int h) {
+	bil_t b;
+	double u = qx - 0.5, v = qy - 0.5;
+	double fu = floor(u), fv = floor(v);
+	b.tx = u - fu;
+	b.ty = v - fv;
+	b.i0 = clampi((int)fu, 0, w - 1);
+	b.i1 = clampi((int)fu + 1, 0, w - 1);
+	b.j0 = clampi((int)fv, 0, h - 1);
+	b.j1 = clampi((int)fv + 1, 0, h - 1);
+	return b;
+}
+
+static double bil_mix(const bil_t *b, double f00, double f10, double f01, double f11) {
+	double a = f00 + b->tx * (f10 - f00);
+	double c = f01 + b->tx * (f11 - f01);
+	return a + b->ty * (c - a);
+}
+
 /* One pixel of main/hmap.cpp:982-1057.  Returns the number of height loads
  * (:1013-1014) executed = the "ray-steps" of BASELINE.md; -1 - steps when the
  * oracle-only step cap fired (the reference would not have terminated). */
@@ -259,7 +293,30 @@ static int64_t shade_pixel(const oracle_cfg *c, const plane_t *pl, v3 c0, v3 c1,
 			if (steps >= c->step_cap) { capped = 1; break; }
 			heightmap_z = heightmap_buf[gridx + (int64_t)gridy * c->heightmap_width];
 			steps += 1;
-			if (int_point.z < heightmap_z + c0.z) {
+			if (c->sampling == 1) {
+				/* bilinear quality mode (see above); qx,qy are the doubles the reference truncates */
+				const int W = c->heightmap_width, H = c->heightmap_height;
+				const double qx = (int_point.x - c0.x) / c->grid_width, qy = -(int_point.y - c0.y) / c->grid_width;
+				const bil_t b = bil_setup(qx, qy, W, H);
+				const double t = bil_mix(&b, heightmap_buf[b.i0 + (int64_t)b.j0 * W] + c0.z, heightmap_buf[b.i1 + (int64_t)b.j0 * W] + c0.z,
+				                         heightmap_buf[b.i0 + (int64_t)b.j1 * W] + c0.z, heightmap_buf[b.i1 + (int64_t)b.j1 * W] + c0.z);
+				if (int_point.z < t) {
+					int64_t red_index = (gridx + (int64_t)gridy * W) * 4;
+					if (colormap_buf[red_index + 3] == 0) {
+						rgba[0] = c->bg_r; rgba[1] = c->bg_g; rgba[2] = c->bg_b;
+					} else {
+						int k;
+						for (k = 0; k < 3; ++k) {
+							const double f = bil_mix(&b, colormap_buf[(b.i0 + (int64_t)b.j0 * W) * 4 + k], colormap_buf[(b.i1 + (int64_t)b.j0 * W) * 4 + k],
+							                         colormap_buf[(b.i0 + (int64_t)b.j1 * W) * 4 + k], colormap_buf[(b.i1 + (int64_t)b.j1 * W) * 4 + k]);
+							rgba[k] = (uint8_t)floor(clampd(f + 0.5, 0.0, 255.0));
+						}
+					}
+					rgba[3] = 255;
+					real_hit = 1;
+					break;
+				}
+			} else if (int_point.z < heightmap_z + c0.z) {
 				int64_t red_index = (gridx + (int64_t)gridy * c->heightmap_width) * 4;
 				if (colormap_buf[red_index + 3] == 0) {
 					rgba[0] = c->bg_r; rgba[1] = c->bg_g; rgba[2] = c->bg_b;

@@ -21,7 +21,7 @@ class OracleCfg(C.Structure):
                 ("cam_pos", C.c_double * 3),
                 ("min_height", C.c_double), ("max_height", C.c_double),
                 ("grid_width", C.c_double), ("step_dist", C.c_double), ("ortho_width", C.c_double),
-                ("bg_r", C.c_uint8), ("bg_g", C.c_uint8), ("bg_b", C.c_uint8), ("pad_", C.c_uint8),
+                ("bg_r", C.c_uint8), ("bg_g", C.c_uint8), ("bg_b", C.c_uint8), ("sampling", C.c_uint8),
                 ("step_cap", C.c_int64)]
 
 
@@ -72,6 +72,7 @@ def make_cfg(cam, params, map_w, map_h, step_cap=DEFAULT_STEP_CAP) -> OracleCfg:
     c.min_height, c.max_height = params.min_height, params.max_height
     c.grid_width, c.step_dist, c.ortho_width = params.grid_width, cam.step_dist, cam.ortho_width
     c.bg_r, c.bg_g, c.bg_b = cam.bg_r, cam.bg_g, cam.bg_b
+    c.sampling = cam.sampling
     c.step_cap = step_cap
     return c
 

@@ -168,3 +168,16 @@ def test_record_key_and_orbit_camera(hmrm, maps):
     # frame 0 is the static pose up to the rounding of 0.9*S*cos(45 deg) vs S/8 + S/2
     c0 = wl.camera(0, 64)
     assert abs(c0.pos[0] - static.pos[0]) < 0.02 * s and abs(c0.pos[1] - static.pos[1]) < 0.02 * s
+
+
+def test_sampling_key(hmrm, maps):
+    """Additive `sampling nearest|bilinear` key (quality mode; the reference always takes the nearest cell)."""
+    hp, cp, *_ = maps
+    base = f"heightmap {hp} colormap {cp} "
+    assert hmrm.Config().consume_string(base).camera().sampling == hmrm.NEAREST
+    cfg = hmrm.Config().consume_string(base + "sampling bilinear")
+    assert cfg.camera().sampling == hmrm.BILINEAR and "sampling bilinear\n" in cfg.log
+    cfg = hmrm.Config().consume_string(base + "sampling bilinear sampling nearest")
+    assert cfg.camera().sampling == hmrm.NEAREST
+    cfg = hmrm.Config().consume_string(base + "sampling cubic")
+    assert cfg.camera().sampling == hmrm.NEAREST and "WARNING: Unknown sampling: cubic" in cfg.warnings

@@ -123,3 +123,75 @@ def test_golden_frames_reproduce(oracle):
         assert np.array_equal(fb, data[name + "/frame"]), name
         assert np.array_equal(steps.astype(np.uint32), data[name + "/steps"]), name
         assert np.array_equal(entry.view(np.uint64), data[name + "/entry_bits"]), name
+
+
+# ---- bilinear quality mode (additive; the oracle is its definition) ----
+
+def test_bilinear_mode_definition(oracle, hmrm):
+    """Top-down orthographic rays make the mode checkable by hand: each ray hits at a known (x, y),
+    so its colour must be the bilinear mix of the four surrounding texels (cell centres at
+    integer + 0.5, edges clamped), rounded with floor(f + 0.5); the step at which it hits is the
+    first sample with z below the interpolated height (+ min_height a second time, hmap.cpp:1016)."""
+    import math
+    rng = np.random.RandomState(5)
+    mw = mh = 12
+    rgb = np.repeat(rng.randint(0, 256, size=(mh, mw, 1)), 3, axis=2).astype(np.uint8)
+    cmap = rng.randint(0, 256, size=(mh, mw, 4)).astype(np.uint8)
+    cmap[:, :, 3] = 255
+    cmap[4, 7, 3] = 0
+    params = hmrm.SceneParams.make(0.0, 6.0, grid_width=1.0)
+    kw = dict(width=31, height=29, projection=3, hang=0.0, vang=hmrm.degrees_to_rads(180), pos=(6.0, -6.0, 50.0),
+              ortho_width=0.41, step_dist=0.125, bg=(9, 8, 7))
+    cam = hmrm.Camera.make(sampling=hmrm.BILINEAR, **kw)
+    heights = oracle.update_heightmap(rgb, params)
+    fb, total, capped, steps, entry = oracle.render(oracle.make_cfg(cam, params, mw, mh), heights, cmap, per_pixel=True)
+    checked = 0
+    for py in range(cam.height):
+        for px in range(cam.width):
+            ray = oracle.probe_ray(oracle.make_cfg(cam, params, mw, mh), px, py)
+            pos, dirv, d = ray
+            if not (d >= 0 and math.isfinite(d)):
+                continue
+            assert abs(dirv[2] + 1.0) < 1e-6, "camera must look straight down"
+            qx, qy = pos[0], -pos[1]
+            if not (0.0 < qx < mw and 0.0 < qy < mh):
+                continue
+            u, v = qx - 0.5, qy - 0.5
+            fu, fv = math.floor(u), math.floor(v)
+            tx, ty = u - fu, v - fv
+            i0, i1 = min(max(int(fu), 0), mw - 1), min(max(int(fu) + 1, 0), mw - 1)
+            j0, j1 = min(max(int(fv), 0), mh - 1), min(max(int(fv) + 1, 0), mh - 1)
+
+            def mix(a00, a10, a01, a11):
+                a = a00 + tx * (a10 - a00)
+                c = a01 + tx * (a11 - a01)
+                return a + ty * (c - a)
+            if cmap[int(qy), int(qx), 3] == 0:
+                exp = [9, 8, 7, 255]
+            else:
+                exp = [int(math.floor(min(max(mix(*(float(cmap[j, i, k]) for j, i in ((j0, i0), (j0, i1), (j1, i0), (j1, i1)))) + 0.5, 0.0), 255.0)))
+                       for k in range(3)] + [255]
+            assert fb[py, px].tolist() == exp, (px, py)
+            t = mix(*(heights[j, i] + params.min_height for j, i in ((j0, i0), (j0, i1), (j1, i0), (j1, i1))))
+            # straight down: z after k steps (the first sample is at the nudged entry point)
+            z0 = 6.0 - 0.01
+            k_hit = max(1, int(math.ceil((z0 - t) / 0.125 + 1e-9)) + 1) if z0 >= t else 1
+            assert abs(int(steps[py, px]) - k_hit) <= 1, (px, py, steps[py, px], k_hit)
+            checked += 1
+    assert checked > 300
+
+
+def test_bilinear_on_flat_map_equals_nearest_and_config_flag_defaults_off(oracle, hmrm):
+    rgb = np.full((16, 16, 3), 90, dtype=np.uint8)
+    cmap = np.full((16, 16, 4), 200, dtype=np.uint8)
+    params = hmrm.SceneParams.make(0.0, 3.0, grid_width=0.5)
+    heights = oracle.update_heightmap(rgb, params)
+    frames = []
+    for sampling in (hmrm.NEAREST, hmrm.BILINEAR):
+        cam = hmrm.Camera.make(width=40, height=30, projection=1, hang=hmrm.degrees_to_rads(-40),
+                               vang=hmrm.degrees_to_rads(115), pos=(-3.0, 3.0, 4.0), step_dist=0.05, sampling=sampling)
+        cfg = oracle.make_cfg(cam, params, 16, 16)
+        assert cfg.sampling == sampling
+        frames.append(oracle.render(cfg, heights, cmap, per_pixel=True))
+    assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][3], frames[1][3])
+    assert hmrm.Camera.make().sampling == hmrm.NEAREST

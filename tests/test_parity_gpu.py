@@ -491,3 +491,118 @@ def test_render_argument_validation(gpu):
     assert lib.hmrm_render(scene._h, C.byref(cam), wide.ctypes.data, 24 * 4) == gpu.HMRM_OK
     assert np.array_equal(wide[:, :16], scene.render(cam)) and (wide[:, 16:] == 9).all()
     scene.close()
+
+
+# ---- bilinear quality mode (additive): defined by the oracle, not the reference ----
+
+def _bilinear(cam):
+    import copy
+    c = copy.copy(cam)
+    c.sampling = 1
+    return c
+
+
+@pytest.mark.parametrize("case", scenes.cases(), ids=scenes.case_ids())
+def test_bilinear_mode_bit_exact(gpu, oracle, case):
+    """`sampling bilinear`: interpolated height test + interpolated colour; every other rule of the
+    loop (entry nudge, range test, sky, alpha-0 on the nearest cell) unchanged.  Leaps run on the
+    3x3-dilated pyramid; frame and per-ray step counts must equal the oracle's."""
+    name, rgb, cmap, params, cam = scenes.build_case(case)
+    cam = _bilinear(cam)
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    cfg = oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0])
+    assert cfg.sampling == 1
+    ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True)
+    for variant in ("leap", "group", "simple"):  # "simple" has no bilinear loop: served by "group"
+        with kernel_variant(variant):
+            fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
+            assert np.array_equal(_bits(entry), _bits(oentry)), variant
+            assert np.array_equal(steps.astype(np.int64), osteps), variant
+            assert np.array_equal(fb, ofb), variant
+            assert (st.rays, st.steps, st.capped) == (cam.width * cam.height, total, 0), variant
+            assert np.array_equal(scene.render(cam), ofb), variant
+    scene.close()
+
+
+def test_bilinear_fuzz_update_and_cache(gpu, oracle):
+    """Seeded fuzz of the bilinear mode (all three grid-width paths, all projections), plus: a height
+    update between two bilinear frames of the same camera rebuilds the dilated pyramid, and
+    nearest/bilinear frames of one scene do not leak state into each other."""
+    rng = np.random.RandomState(77)
+    os.environ["HMRM_STEP_CAP"] = "400000"
+    leaped = differs = 0
+    try:
+        for trial in range(30):
+            mw, mh = int(rng.choice([48, 96, 160, 257])), int(rng.choice([48, 96, 131]))
+            rgb, cmap = scenes.small_maps(mw, mh, 3000 + trial, color_heights=bool(trial % 3 == 0))
+            gw = float(rng.choice([1.0, 0.5, 0.05, 0.3, 1.7]))
+            lo = float(rng.choice([0.0, -1.5, 2.0]))
+            hi = lo + float(rng.uniform(0.5, 0.3 * mw)) * gw
+            params = gpu.SceneParams.make(lo, hi, grid_width=gw)
+            ext_x, ext_y = mw * gw, mh * gw
+            ang = rng.uniform(0, 2 * np.pi)
+            dist = rng.uniform(0.2, 1.6) * max(ext_x, ext_y)
+            pos = (ext_x / 2 + dist * np.cos(ang), -ext_y / 2 + dist * np.sin(ang), hi + rng.uniform(-0.5, 2.0) * (hi - lo + gw))
+            hang = float(np.arctan2(-ext_y / 2 - pos[1], ext_x / 2 - pos[0]) + rng.uniform(-0.4, 0.4))
+            cam = gpu.Camera.make(width=int(rng.randint(17, 90)), height=int(rng.randint(9, 70)),
+                                  projection=int(rng.choice([1, 2, 3])),
+                                  hfov=float(gpu.degrees_to_rads(rng.uniform(30, 175))), hang=hang,
+                                  vang=float(gpu.degrees_to_rads(rng.uniform(60, 170))), pos=pos,
+                                  ortho_width=float(rng.uniform(0.2, 3.0) * gw),
+                                  step_dist=float(rng.choice([0.05, 0.1, 0.25, 0.5, 0.37]) * gw),
+                                  bg=tuple(int(v) for v in rng.randint(0, 256, size=3)), sampling=gpu.BILINEAR)
+            near_cam = gpu.Camera.make(width=cam.width, height=cam.height, projection=cam.projection, hfov=cam.hfov,
+                                       hang=cam.hang, vang=cam.vang, pos=tuple(cam.pos), ortho_width=cam.ortho_width,
+                                       step_dist=cam.step_dist, bg=(cam.bg_r, cam.bg_g, cam.bg_b))
+            heights = oracle.update_heightmap(rgb, params)
+            ofb, total, capped, osteps, _ = oracle.render(oracle.make_cfg(cam, params, mw, mh, step_cap=400000),
+                                                          heights, cmap, per_pixel=True)
+            onear, *_ = oracle.render(oracle.make_cfg(near_cam, params, mw, mh, step_cap=400000), heights, cmap)
+            scene = gpu.Scene(rgb, cmap, params)
+            fb, st, steps, _ = scene.render_stats(cam, per_pixel=True, allow_capped=True)
+            assert np.array_equal(fb, ofb), trial
+            if capped == 0:
+                assert np.array_equal(steps.astype(np.int64), osteps) and st.steps == total, trial
+            assert st.capped == capped, trial
+            if capped == 0:
+                assert np.array_equal(scene.render(near_cam), onear), trial
+                assert np.array_equal(scene.render(cam), ofb), trial
+            leaped += st.leaped_steps
+            differs += int(not np.array_equal(ofb, onear))
+            if trial % 5 == 0 and capped == 0:
+                # new heights, same camera: the cached frame and the dilated pyramid must both refresh
+                params2 = gpu.SceneParams.make(lo, lo + 0.5 * (hi - lo), grid_width=gw)
+                scene.update(params2)
+                h2 = oracle.update_heightmap(rgb, params2)
+                cfg2 = oracle.make_cfg(cam, params2, mw, mh, step_cap=400000)
+                o2, _, cap2, *_ = oracle.render(cfg2, h2, cmap)
+                if cap2 == 0:
+                    assert np.array_equal(scene.render(cam), o2), trial
+            scene.close()
+    finally:
+        del os.environ["HMRM_STEP_CAP"]
+    assert leaped > 0 and differs > 20
+
+
+def test_bilinear_full_size_c3_subsampled(gpu, oracle):
+    """BASELINE's C3 frame in bilinear mode: every 48th row against the oracle, determinism, and the
+    instrumented kernel writes the same frame as the plain one."""
+    wl = gpu.synth.WORKLOADS["C3"]
+    rgb, cmap = gpu.synth.synth_maps(wl.map_size)
+    params, cam = wl.scene_params(), wl.camera()
+    cam.sampling = gpu.BILINEAR
+    scene = gpu.Scene(rgb, cmap, params)
+    fb = scene.render(cam)
+    assert np.array_equal(fb, scene.render(cam))
+    fbs, st, steps, _ = scene.render_stats(cam, per_pixel=True)
+    assert np.array_equal(fbs, fb) and st.capped == 0 and st.leaped_steps > 0
+    heights = oracle.update_heightmap(rgb, params)
+    cfg = oracle.make_cfg(cam, params, wl.map_size, wl.map_size)
+    stride = 48
+    ofb, total, capped, osteps, _ = oracle.render(cfg, heights, cmap, per_pixel=True, row_stride=stride)
+    rows = slice(0, cam.height, stride)
+    assert capped == 0
+    assert np.array_equal(fb[rows], ofb[rows])
+    assert np.array_equal(steps[rows].astype(np.int64), osteps[rows])
+    scene.close()
