@@ -186,7 +186,7 @@ int prepare_frame(hmrm_scene *s, const hmrm_camera *cam, hipStream_t stream, hmr
 	f->step_cap = default_step_cap();
 	{
 		const char *dg = getenv("HMRM_DIAG_ITERS");
-		f->diag_mode = (dg && dg[0] >= '1' && dg[0] <= '3') ? dg[0] - '0' : 0;
+		f->diag_mode = dg ? atoi(dg) : 0;
 	}
 	return HMRM_OK;
 }
@@ -238,7 +238,11 @@ int prepare_frame_uncached(hmrm_scene *s, const hmrm_camera *cam, hipStream_t st
 	// per pixel instead of the step count (tools/ only)
 	{
 		const char *dg = getenv("HMRM_DIAG_ITERS");
-		f->diag_mode = (dg && dg[0] >= '1' && dg[0] <= '3') ? dg[0] - '0' : 0;
+		f->diag_mode = dg ? atoi(dg) : 0;
+	}
+	{
+		const char *ml = getenv("HMRM_MIN_LEVEL"); // tools only: override the finest level used
+		if (ml && ml[0] >= '0' && ml[0] < '0' + hmrm::kMipLevels) f->min_level = ml[0] - '0';
 	}
 	for (int l = 0; l < hmrm::kMipLevels; ++l) {
 		f->mipbuf = s->d_mipbuf;

@@ -139,6 +139,13 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min
 	f->grid_pow2 = (std::isfinite(grid_width) && m == 0.5 && e > -1000 && e < 1000) ? 1 : 0;
 	f->inv_grid_width = 1.0 / grid_width;
 	f->grid_mode = grid_width == 1.0 ? 0 : (f->grid_pow2 ? 1 : 2);
+
+	// Scheduling hint only (never changes a pixel): the finest pyramid level has 4-cell windows
+	// placed every 2 cells, i.e. 2..4 cells of room; with steps longer than about a third of a
+	// cell that is too few steps for a jump to pay for its bookkeeping (measured: C3 at 0.25
+	// cells/step wants level 0, C2/C4/C5 at 0.5 run 5-7 % faster without it).
+	const double cells_per_step = std::fabs(cam.step_dist / grid_width);
+	f->min_level = cells_per_step > 0.35 ? 1 : 0;
 }
 
 } // namespace hmrm

@@ -103,6 +103,27 @@ __device__ __forceinline__ bool slab_surely_misses(const DevRay &r, const DevFra
 	return HI < 0.0 || (LO - HI) > mag * 0x1p-12;
 }
 
+// Cheaper still, from sign and exponent bits alone: on some axis the whole box lies on one
+// side of the origin (c0-o and c1-o have the same sign) and the ray points the other way.
+// With all three numbers finite, non-zero and of moderate exponent (2^-500 .. 2^499) both
+// exact quotients are finite, non-zero and negative, so that axis' dim_hi < 0 and
+// distance() (AABB.cpp:49-77) ends in inf or in an entry distance <= hi < 0: a miss.
+__device__ __forceinline__ bool slab_points_away(const DevRay &r, const DevFrame &f) {
+	const double ro[3] = {r.px, r.py, r.pz};
+	const double rd[3] = {r.dx, r.dy, r.dz};
+	bool away = false;
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		const uint32_t h0 = (uint32_t)((unsigned long long)__double_as_longlong(f.c0[i] - ro[i]) >> 32);
+		const uint32_t h1 = (uint32_t)((unsigned long long)__double_as_longlong(f.c1[i] - ro[i]) >> 32);
+		const uint32_t hd = (uint32_t)((unsigned long long)__double_as_longlong(rd[i]) >> 32);
+		const bool moderate = (((h0 >> 20) & 0x7ffu) - 523u) < 1000u && (((h1 >> 20) & 0x7ffu) - 523u) < 1000u &&
+		                      (((hd >> 20) & 0x7ffu) - 523u) < 1000u;
+		away = away || (moderate && ((h0 ^ h1) >> 31) == 0u && ((h0 ^ hd) >> 31) != 0u);
+	}
+	return away;
+}
+
 __device__ __forceinline__ uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b) {
 	return r | (g << 8) | (b << 16) | 0xff000000u; // bytes R,G,B,A=255 (hmap.cpp:150-153)
 }

@@ -48,6 +48,8 @@ struct DevFrame {
 	int32_t mip_off[4];
 	int32_t diag_mode;           // tools only: what the instrumented kernel writes per pixel
 	int32_t sampling;            // 0 nearest cell (the reference), 1 bilinear quality mode
+	int32_t min_level;           // finest pyramid level worth an attempt (camera.cpp)
+	int32_t pad3_;
 };
 
 constexpr int kMipLevels = 4;

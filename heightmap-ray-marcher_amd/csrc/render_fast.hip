@@ -45,6 +45,7 @@ constexpr int kGroup = 4;       // U: positions per speculative group
 #endif
 constexpr int kMinLeap = HMRM_MIN_LEAP; // a jump shorter than this is not worth its bookkeeping
 constexpr int kTopLevel = kMipLevels; // whole-map level (thr_max, no load)
+constexpr double kUpRatio = 4.0;      // see the level policy in k_render_fast
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
 __device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)(unsigned long long)__double_as_longlong(v); }
@@ -187,12 +188,14 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 	uint32_t my_hit = 0, my_cap = 0;
 	uint32_t dg_attempts = 0, dg_leaps = 0, dg_groups = 0; // STATS-only diagnostics
 	unsigned long long dg_leaped = 0;
+	unsigned long long dg_x0 = 0, dg_x1 = 0, dg_x2 = 0, dg_x3 = 0;
 
 	if (pid.live) {
 		const DevRay ray = make_ray<PROJ>(f, pid.px, pid.py);
 		// most rays of a frame never touch the box: prove the miss cheaply where possible
 		// (the instrumented variant always runs the exact test, it reports d)
-		const double d = (!STATS && slab_surely_misses(ray, f)) ? __builtin_huge_val() : slab_distance(ray, f);
+		const double d = (!STATS && (slab_points_away(ray, f) || slab_surely_misses(ray, f))) ? __builtin_huge_val()
+		                                                                                  : slab_distance(ray, f);
 		if (STATS && st.entry_d) st.entry_d[(int64_t)pid.py * f.screen_w + pid.px] = d;
 
 		uint32_t rgba = 0;
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						double room = (ax.lim - x) * ax.rdel;
 						room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
 						room = __builtin_fmin(room, (az.lim - z) * az.rdel);
+						const double room_b = room; // steps left inside the three binades
 						room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
 						room = __builtin_fmin(room, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
 						room = __builtin_fmin(room, (double)budget);
@@ -290,25 +294,80 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						y = ok ? yn : y;
 						z = ok ? zn : z;
 						budget -= ok ? n : 0;
+						if (STATS && f.diag_mode == 4) {
+							const bool ie = inb0 && exact;
+							dg_x0 += (ie && !above) ? 1u : 0u;
+							dg_x1 += (ie && above && n < kMinLeap && z_bound) ? 1u : 0u;
+							dg_x2 += (ie && above && n < kMinLeap && !z_bound) ? 1u : 0u;
+							dg_x3 += (can && !ok) ? 1u : 0u;
+						}
+						if (STATS && f.diag_mode == 1 + 8) {
+							const bool sl = inb0 && exact && above && n < kMinLeap && !z_bound;
+							dg_x0 += (sl && lev == 0) ? 1u : 0u;
+							dg_x1 += (sl && lev == 1) ? 1u : 0u;
+							dg_x2 += (sl && lev == 2) ? 1u : 0u;
+							dg_x3 += (sl && lev >= 3) ? 1u : 0u;
+						}
+						if (STATS && f.diag_mode == 2 + 8) {
+							const bool sl = inb0 && exact && above && n < kMinLeap && !z_bound;
+							const double rbx = (ax.lim - x) * ax.rdel, rby = (ay.lim - y) * ay.rdel, rbz = (az.lim - z) * az.rdel;
+							const double rwx = sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40, rwy = sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40;
+							const double rb = __builtin_fmin(rbx, __builtin_fmin(rby, rbz));
+							const double rw = __builtin_fmin(rwx, rwy);
+							dg_x0 += (sl && rb < rw) ? 1u : 0u;       // binade-limited
+							dg_x1 += (sl && rb >= rw && rwx <= rwy) ? 1u : 0u; // window x edge
+							dg_x2 += (sl && rb >= rw && rwx > rwy) ? 1u : 0u;  // window y edge
+							dg_x3 += (sl && rbz <= rb && rb < rw) ? 1u : 0u;   // of the binade ones: z
+						}
+						if (STATS && f.diag_mode == 3 + 8) {
+							const bool bm = inb0 && exact && !above;
+							dg_x0 += (bm && lev == 0) ? 1u : 0u;
+							dg_x1 += (bm && lev == 1) ? 1u : 0u;
+							dg_x2 += (bm && lev == 2) ? 1u : 0u;
+							dg_x3 += (bm && lev == 3) ? 1u : 0u;
+						}
+						if (STATS && f.diag_mode == 5) {
+							dg_x0 += (lev == 0) ? 1u : 0u;
+							dg_x1 += (lev == 1) ? 1u : 0u;
+							dg_x2 += (lev == 2) ? 1u : 0u;
+							dg_x3 += (lev == 3) ? 1u : 0u;
+						}
+						if (STATS && f.diag_mode == 6) {
+							dg_x0 += (ok && lev == 0) ? 1u : 0u;
+							dg_x1 += (ok && lev == 1) ? 1u : 0u;
+							dg_x2 += (ok && lev == 2) ? 1u : 0u;
+							dg_x3 += (ok && lev == 3) ? 1u : 0u;
+						}
+						if (STATS && f.diag_mode == 7) {
+							dg_x0 += (ok && lev == 0) ? (unsigned)n : 0u;
+							dg_x1 += (ok && lev == 1) ? (unsigned)n : 0u;
+							dg_x2 += (ok && lev == 2) ? (unsigned)n : 0u;
+							dg_x3 += (ok && lev == 3) ? (unsigned)n : 0u;
+						}
 						if (STATS) {
 							my_steps += ok ? (unsigned)n : 0u;
 							dg_leaped += ok ? (unsigned)n : 0u;
 							dg_leaps += ok ? 1u : 0u;
 						}
 						// level policy (performance only; any policy gives the same pixels):
-						//   window crossed                    -> coarser next time
+						//   window crossed                    -> coarser next time, if the height bound of this
+						//                                        level left room for a window kUpRatio times
+						//                                        longer (a coarser maximum is no lower)
+						//   jump ended at a binade boundary   -> same level, and march a group first
 						//   height bound was the limit        -> finer; without a jump retry at once (the
 						//     (z < max, or z-room smallest)      level strictly decreases); at the finest
 						//                                        level march two groups before looking again
 						//   no lateral/binade room, not exact -> coarser (a bigger window has more room),
 						//                                        growing pause while attempts keep failing
+						const bool binade_bound = room_b <= room;
 						const bool height_limited = inb0 && exact && (!above || z_bound);
 						const int coarser = lev >= kMipLevels - 1 ? kMipLevels - 1 : lev + 1;
-						const int finer = top ? kMipLevels - 1 : (lev > 0 ? lev - 1 : 0);
-						const bool at_finest = lev == 0;
+						const int minlev = f.min_level;
+						const int finer = top ? kMipLevels - 1 : (lev > minlev ? lev - 1 : minlev);
+						const bool at_finest = lev == minlev;
 						if (ok && !z_bound) {
 							fails = 0;
-							lev = coarser;
+							lev = (room_z >= kUpRatio * room && !binade_bound) ? coarser : lev;
 						} else if (height_limited) {
 							fails = ok ? 0 : fails;
 							skip_group = !ok && !at_finest; // retry one level down without marching
@@ -319,7 +378,9 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 							++fails;
 							lev = coarser;
 						}
-						skip_group = skip_group || ok; // after a jump look at the next window straight away
+						// after a jump look at the next window straight away -- unless the jump stopped at a
+						// binade boundary: only real steps cross it, another attempt here would just fail
+						skip_group = skip_group || (ok && !binade_bound);
 					}
 				}
 				if (skip_group) continue;
@@ -425,6 +486,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 	publish_counters<STATS>(st, my_steps, my_hit, my_cap);
 	if (STATS) {
 		unsigned long long a = dg_attempts, l = dg_leaps, g = dg_groups, s = dg_leaped;
+		if (f.diag_mode >= 4) { a = dg_x0; l = dg_x1; g = dg_x2; s = dg_x3; }
 		for (int off = 32; off > 0; off >>= 1) {
 			a += __shfl_xor(a, off);
 			l += __shfl_xor(l, off);

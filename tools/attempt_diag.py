@@ -1,0 +1,20 @@
+"""Why leap attempts fail and at which pyramid level (instrumented kernel, HMRM_DIAG_ITERS=4..11)."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+hm = importlib.import_module("heightmap-ray-marcher_amd")
+for name in sys.argv[1:] or ["C3", "C5"]:
+    wl = hm.synth.WORKLOADS[name]
+    rgb, cmap = hm.synth.synth_maps(wl.map_size)
+    scene = hm.Scene(rgb, cmap, wl.scene_params())
+    cam = wl.camera()
+    _, st, *_ = scene.render_stats(cam)
+    print(name, "attempts", st.leap_attempts, "leaps", st.leaps, "groups", st.groups, "leaped", st.leaped_steps, "steps", st.steps)
+    for mode, labels in ((4, ("below max", "short z-bound", "short lateral", "verify failed")), (5, ("att L0", "att L1", "att L2", "att L3")),
+                         (6, ("ok L0", "ok L1", "ok L2", "ok L3")), (7, ("steps L0", "steps L1", "steps L2", "steps L3")),
+                         (9, ("shortlat L0", "L1", "L2", "L3+")), (10, ("binade", "win x", "win y", "binade z")), (11, ("below L0", "L1", "L2", "L3"))):
+        os.environ["HMRM_DIAG_ITERS"] = str(mode)
+        cam.bg_r = mode  # defeat the frame cache
+        _, s2, *_ = scene.render_stats(cam)
+        print("  ", dict(zip(labels, (s2.leap_attempts, s2.leaps, s2.groups, s2.leaped_steps))))
+    os.environ.pop("HMRM_DIAG_ITERS")
+    scene.close()
