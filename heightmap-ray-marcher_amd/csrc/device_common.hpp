@@ -179,7 +179,10 @@ struct PixelId {
 	bool live;
 };
 __device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap &rows, int tiles_x) {
-	const int tile = blockIdx.x;
+	// launch order rotated so that the costliest tile rows start first (RowMap::tile_rot)
+	unsigned t = blockIdx.x + (unsigned)rows.tile_rot;
+	if (t >= gridDim.x) t -= gridDim.x;
+	const int tile = (int)t;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	PixelId p;

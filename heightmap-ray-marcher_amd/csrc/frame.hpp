@@ -61,6 +61,7 @@ struct RowMap {
 	int32_t local_rows;    // rows held by the output buffer
 	int32_t band_rows;     // 0 = contiguous; else cyclic bands of this many rows
 	int32_t band_index, band_count;
+	int32_t tile_rot;      // launch order: workgroup i renders tile (i + tile_rot) mod n_tiles (api.cpp)
 };
 
 // Host: fill everything except the table pointers / thr_max / step_cap.
@@ -77,5 +78,11 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h,
                  DevFrame *out,
                  double *col_cos_ha, double *col_sin_ha,   // width entries each (spherical) or null
                  double *row_sin_va, double *row_cos_va);  // height entries each (spherical) or null
+
+// Scheduling aid, approximate arithmetic: for every block of `rows_per_sample` screen rows the
+// longest in-box ray length (in steps) over a few sample columns of the block's middle row.
+// out has ceil(screen_h / rows_per_sample) entries.  Tables as filled by build_frame.
+void estimate_row_costs(const DevFrame &f, const double *col_cos_ha, const double *col_sin_ha,
+                        const double *row_sin_va, const double *row_cos_va, int rows_per_sample, float *out);
 
 } // namespace hmrm

@@ -37,6 +37,9 @@ hipError_t launch_build_mip0(const double *d_thr, int map_w, int map_h, float *d
 hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *d_dst, int dst_w, int dst_h,
                                hipStream_t stream);
 
+// Pixel tile (= workgroup) shape of launch_render / launch_render_fast.
+void render_tile_shape(int *tile_w, int *tile_h);
+
 // GetRay + distance() of pixel (px,py): d_out7 = pos[3], dir[3], d.
 hipError_t launch_probe(const DevFrame &f, int px, int py, double *d_out7, hipStream_t stream);
 

@@ -39,7 +39,10 @@ namespace hmrm {
 
 namespace {
 
-constexpr int kGroup = 4;       // U: positions per speculative group
+#ifndef HMRM_GROUP
+#define HMRM_GROUP 4
+#endif
+constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group
 #ifndef HMRM_MIN_LEAP
 #define HMRM_MIN_LEAP 6
 #endif
@@ -234,12 +237,14 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 			bool done = entry_nan;
 			while (!done) {
 				bool skip_group = false;
+				bool dg_attempted = false; // diagnostics only
 				// ---------------------------------------------------------- leap
 				if (LEAP) {
 					const bool attempt = cooldown == 0;
 					cooldown -= attempt ? 0 : 1;
 					if (attempt) {
 						if (STATS) ++dg_attempts;
+						dg_attempted = true;
 						if ((hi32(x) >> 20) != ax.key) axis_refresh(ax, x, sx);
 						if ((hi32(y) >> 20) != ay.key) axis_refresh(ay, y, sy);
 						if ((hi32(z) >> 20) != az.key) axis_refresh(az, z, sz);
@@ -383,6 +388,28 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						skip_group = skip_group || (ok && !binade_bound);
 					}
 				}
+				if (STATS && f.diag_mode == 12) { // wave-level view of the loop: who runs which block
+					const unsigned long long act = __ballot(true);
+					const unsigned long long att = __ballot(LEAP && dg_attempted);
+					const unsigned long long grp = __ballot(!skip_group);
+					if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
+						dg_x0 += 1u;
+						dg_x1 += att ? 1u : 0u;
+						dg_x2 += grp ? 1u : 0u;
+						dg_x3 += (unsigned)__popcll(act);
+					}
+				}
+				if (STATS && f.diag_mode == 13) { // lanes doing useful work in each block
+					const unsigned long long att = __ballot(LEAP && dg_attempted);
+					const unsigned long long grp = __ballot(!skip_group);
+					const unsigned long long act = __ballot(true);
+					if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
+						dg_x0 += att ? 64u : 0u;                    // lane slots spent in attempt blocks
+						dg_x1 += (unsigned)__popcll(att);           // ... of which useful
+						dg_x2 += grp ? 64u : 0u;                    // lane slots spent in group blocks
+						dg_x3 += (unsigned)__popcll(grp);           // ... of which useful
+					}
+				}
 				if (skip_group) continue;
 
 				// --------------------------------------------- speculative group
@@ -431,19 +458,26 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 				}
 				if (budget >= kGroup) {
 					// in order: the first position that leaves the grid (:1006) or hits (:1016) ends the ray
-					const bool h0 = inb[0] && Z[0] < T[0], h1 = inb[1] && Z[1] < T[1];
-					const bool h2 = inb[2] && Z[2] < T[2], h3 = inb[3] && Z[3] < T[3];
-					const bool s0 = !inb[0] || h0, s1 = !inb[1] || h1, s2 = !inb[2] || h2, s3 = !inb[3] || h3;
-					const int first = s0 ? 0 : (s1 ? 1 : (s2 ? 2 : (s3 ? 3 : 4)));
-					const bool hit = s0 ? h0 : (s1 ? h1 : (s2 ? h2 : (s3 ? h3 : false)));
-					const int hit_cell = s0 ? cell[0] : (s1 ? cell[1] : (s2 ? cell[2] : cell[3]));
+					int first = kGroup, hit_cell = 0, hit_j = 0;
+					bool hit = false;
+#pragma unroll
+					for (int j = kGroup - 1; j >= 0; --j) { // (selects, last write = earliest position)
+						const bool h = inb[j] && Z[j] < T[j];
+						const bool s = !inb[j] || h;
+						first = s ? j : first;
+						hit = s ? h : hit;
+						hit_cell = s ? cell[j] : hit_cell;
+						hit_j = s ? j : hit_j;
+					}
 					const int taken = first + (hit ? 1 : 0); // loads the reference executed in this group
 					budget -= taken;
 					if (STATS) my_steps += (unsigned)taken;
 					done = first < kGroup;
 					if (hit) {
 						if (BILINEAR) {
-							const Bil hb = s0 ? bil[0] : (s1 ? bil[1] : (s2 ? bil[2] : bil[3]));
+							Bil hb = bil[0];
+#pragma unroll
+							for (int j = 1; j < kGroup; ++j) hb = hit_j == j ? bil[j] : hb;
 							rgba = shade_hit_bilinear(f, cmap, hit_cell, hb);
 						} else {
 							rgba = shade_hit(f, cmap[hit_cell]);
@@ -649,6 +683,11 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream);
 	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream);
 	return hipGetLastError();
+}
+
+void render_tile_shape(int *tile_w, int *tile_h) {
+	*tile_w = kTileW;
+	*tile_h = kTileH;
 }
 
 } // namespace hmrm

@@ -606,3 +606,38 @@ def test_bilinear_full_size_c3_subsampled(gpu, oracle):
     assert np.array_equal(fb[rows], ofb[rows])
     assert np.array_equal(steps[rows].astype(np.int64), osteps[rows])
     scene.close()
+
+
+def test_launch_order_never_changes_a_pixel(gpu, oracle):
+    """The cost-rotated launch order (api.cpp choose_tile_rot) is scheduling only: HMRM_TILE_ORDER=0
+    (row-major) and the default order give identical frames, counters and strips; checked where the
+    rotation is non-trivial (horizon in mid-frame) and on a row strip that starts past it."""
+    import torch
+    rgb, cmap = scenes.small_maps(160, 131, 4242)
+    params = gpu.SceneParams.make(0.0, 12.0, grid_width=1.0)
+    heights = oracle.update_heightmap(rgb, params)
+    for proj, vang in ((2, 95.0), (1, 80.0), (3, 120.0)):
+        cam = gpu.Camera.make(width=203, height=157, projection=proj, hfov=gpu.degrees_to_rads(150 if proj == 2 else 80),
+                              hang=gpu.degrees_to_rads(-45), vang=gpu.degrees_to_rads(vang), pos=(-20.0, 20.0, 30.0),
+                              ortho_width=1.1, step_dist=0.25, bg=(1, 2, 3))
+        ofb, total, capped, *_ = oracle.render(oracle.make_cfg(cam, params, 160, 131), heights, cmap)
+        assert capped == 0
+        frames = {}
+        for order in ("0", "1"):
+            os.environ["HMRM_TILE_ORDER"] = order
+            try:
+                scene = gpu.Scene(rgb, cmap, params)
+                fb, st, *_ = scene.render_stats(cam)
+                buf = torch.zeros((131 - 48, cam.width, 4), dtype=torch.uint8, device="cuda")
+                scene.render_rows_device(cam, buf.data_ptr(), cam.width * 4, 48, 131,
+                                         stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                strip = buf.cpu().numpy()
+                frames[order] = (fb, st.steps, scene.render(cam), strip)
+                scene.close()
+            finally:
+                del os.environ["HMRM_TILE_ORDER"]
+        for order in ("0", "1"):
+            fb, steps, plain, strip = frames[order]
+            assert np.array_equal(fb, ofb) and np.array_equal(plain, ofb) and steps == total, (proj, order)
+            assert np.array_equal(strip, ofb[48:131]), (proj, order)
