@@ -146,32 +146,34 @@ struct Axis {
 // Invalid (key = ~0) also when the two steps leave the binade or change sign, or p is
 // tiny / non-finite.
 __device__ __forceinline__ void axis_refresh(Axis &a, double p, double s) {
+	// straight-line on purpose (bitwise tests, selects): a wave runs this whenever any lane
+	// crosses a binade, so exec-mask branches here would cost every lane of the wave
 	const double p1 = p + s, p2 = p1 + s;
 	const uint32_t hp = hi32(p), hp1 = hi32(p1), hp2 = hi32(p2);
 	const uint32_t e = (hp >> 20) & 0x7ffu;
 	const double d = p1 - p;                  // exact: multiples of u, |d| < 2^53 u
-	const bool ok = ((hp ^ hp1) >> 20) == 0 && ((hp ^ hp2) >> 20) == 0 && e >= 128u && e <= 1900u &&
-	                (p2 - p1) == d;
+	const int ok = (int)((((hp ^ hp1) | (hp ^ hp2)) >> 20) == 0u) & (int)(e - 128u <= 1772u) & (int)((p2 - p1) == d);
 	a.key = ok ? (hp >> 20) : 0xffffffffu;
 	a.delta = d;
-	if (d == 0.0) { // the coordinate never moves (s == 0 or absorbed): unlimited room
-		a.lim = p + 1.0;
-		a.rdel = 0x1p40;
-	} else {
-		const double lo = f64_from_hi(hp & 0x7ff00000u);          // 2^E
-		const bool away = ((hi32(d) ^ hp) >> 31) == 0;            // |p| grows
-		const double lim_abs = away ? lo + lo : lo;
-		a.lim = (hp >> 31) ? -lim_abs : lim_abs;
-		a.rdel = __builtin_amdgcn_rcp(d);
-	}
+	// |p| grows (d has p's sign): the limit is 2^(E+1), else 2^E; either way with p's sign.
+	// One integer add on the high word (E <= 1900, no overflow into the sign).
+	const uint32_t away = (((hi32(d) ^ hp) >> 31) ^ 1u) << 20;
+	const double lim = f64_from_hi((hp & 0xfff00000u) + away);
+	const bool still = d == 0.0;              // the coordinate never moves (s == 0 or absorbed): unlimited room
+	a.lim = still ? p + 1.0 : lim;
+	a.rdel = still ? 0x1p40 : __builtin_amdgcn_rcp(d);
 }
 
 // p_n = p + n*delta is trustworthy iff it is still in p's binade with the same sign,
 // and -- when the coordinate moves -- not exactly on a binade boundary (moving towards
 // zero, the step that produced it could have rounded on the finer grid below 2^E).
 __device__ __forceinline__ bool axis_landing_ok(const Axis &a, double pn) {
-	if ((hi32(pn) >> 20) != a.key) return false;
-	return a.delta == 0.0 || (hi32(pn) & 0xfffffu) != 0u || lo32(pn) != 0u;
+	// (bitwise on purpose: one straight-line expression instead of a chain of exec-mask branches)
+	const uint32_t h = hi32(pn);
+	const int same_binade = (h >> 20) == a.key ? 1 : 0;
+	const int off_boundary = ((h & 0xfffffu) | lo32(pn)) != 0u ? 1 : 0;
+	const int still = a.delta == 0.0 ? 1 : 0;
+	return (same_binade & (still | off_boundary)) != 0;
 }
 
 } // namespace
@@ -370,19 +372,16 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						const int minlev = f.min_level;
 						const int finer = top ? kMipLevels - 1 : (lev > minlev ? lev - 1 : minlev);
 						const bool at_finest = lev == minlev;
-						if (ok && !z_bound) {
-							fails = 0;
-							lev = (room_z >= kUpRatio * room && !binade_bound) ? coarser : lev;
-						} else if (height_limited) {
-							fails = ok ? 0 : fails;
-							skip_group = !ok && !at_finest; // retry one level down without marching
-							cooldown = (!ok && at_finest) ? 1 : 0;
-							lev = finer;
-						} else {
-							cooldown = fails < 3 ? fails : 3;
-							++fails;
-							lev = coarser;
-						}
+						// (selects, not branches: the three cases are mutually exclusive)
+						const bool crossed = ok && !z_bound;
+						const bool hl = !crossed && height_limited;
+						const bool other = !crossed && !hl;
+						const bool go_up = crossed ? (room_z >= kUpRatio * room && !binade_bound) : other;
+						const int fails_before = fails;
+						lev = hl ? finer : (go_up ? coarser : lev);
+						fails = (crossed || (hl && ok)) ? 0 : (other ? fails + 1 : fails);
+						cooldown = hl ? ((!ok && at_finest) ? 1 : 0) : (other ? (fails_before < 3 ? fails_before : 3) : 0);
+						skip_group = hl && !ok && !at_finest; // retry one level down without marching
 						// after a jump look at the next window straight away -- unless the jump stopped at a
 						// binade boundary: only real steps cross it, another attempt here would just fail
 						skip_group = skip_group || (ok && !binade_bound);
