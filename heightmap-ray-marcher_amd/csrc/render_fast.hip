@@ -444,12 +444,11 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 					inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;      // hmap.cpp:1006-1011
 					cell[j] = inb[j] ? gy * f.map_w + gx : 0;
 				}
-				Bil bil[kGroup];
 				if (BILINEAR) {
 #pragma unroll
 					for (int j = 0; j < kGroup; ++j) {
-						bil[j] = bil_setup(inb[j] ? QX[j] : 0.0, inb[j] ? QY[j] : 0.0, f.map_w, f.map_h);
-						T[j] = bil_mix(bil[j], thr[bil[j].c00], thr[bil[j].c10], thr[bil[j].c01], thr[bil[j].c11]);
+						const Bil b = bil_setup(inb[j] ? QX[j] : 0.0, inb[j] ? QY[j] : 0.0, f.map_w, f.map_h);
+						T[j] = bil_mix(b, thr[b.c00], thr[b.c10], thr[b.c01], thr[b.c11]);
 					}
 				} else {
 #pragma unroll
@@ -474,29 +473,51 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 					done = first < kGroup;
 					if (hit) {
 						if (BILINEAR) {
-							Bil hb = bil[0];
+							// (the weights are rebuilt for the one position that hit: cheaper than keeping
+							// kGroup sets of them alive)
+							double qxh = QX[0], qyh = QY[0];
 #pragma unroll
-							for (int j = 1; j < kGroup; ++j) hb = hit_j == j ? bil[j] : hb;
-							rgba = shade_hit_bilinear(f, cmap, hit_cell, hb);
+							for (int j = 1; j < kGroup; ++j) {
+								qxh = hit_j == j ? QX[j] : qxh;
+								qyh = hit_j == j ? QY[j] : qyh;
+							}
+							rgba = shade_hit_bilinear(f, cmap, hit_cell, bil_setup(qxh, qyh, f.map_w, f.map_h));
 						} else {
 							rgba = shade_hit(f, cmap[hit_cell]);
 						}
 						real_hit = true;
 					}
 				} else {
-					// (almost never) close to the step cap: one position at a time, cap checked per step
-#pragma unroll
+					// (almost never) close to the step cap: the literal loop, one position at a time, cap
+					// checked per step; a real loop over scalars so that none of the group's arrays is
+					// indexed dynamically
+					double xs = x, ys = y, zs = z;
+#pragma unroll 1
 					for (int j = 0; j < kGroup; ++j) {
-						if (!inb[j]) { done = true; break; }
+						const double qx = (GWM == 0) ? xs : xs / f.grid_width, qy = (GWM == 0) ? -ys : -ys / f.grid_width;
+						const int gx = cvt_i32_sat(qx), gy = cvt_i32_sat(qy);
+						if (!((unsigned)gx < wlim && (unsigned)gy < hlim)) { done = true; break; }
 						if (budget <= 0) { my_cap = 1; done = true; break; }
 						--budget;
 						if (STATS) my_steps += 1;
-						if (Z[j] < T[j]) { // hmap.cpp:1016
-							rgba = BILINEAR ? shade_hit_bilinear(f, cmap, cell[j], bil[j]) : shade_hit(f, cmap[cell[j]]);
+						const int c = gy * f.map_w + gx;
+						Bil b{};
+						double t;
+						if (BILINEAR) {
+							b = bil_setup(qx, qy, f.map_w, f.map_h);
+							t = bil_mix(b, thr[b.c00], thr[b.c10], thr[b.c01], thr[b.c11]);
+						} else {
+							t = thr[c];
+						}
+						if (zs < t) { // hmap.cpp:1016
+							rgba = BILINEAR ? shade_hit_bilinear(f, cmap, c, b) : shade_hit(f, cmap[c]);
 							real_hit = true;
 							done = true;
 							break;
 						}
+						xs += sx;
+						ys += sy;
+						zs += sz;
 					}
 				}
 				x = X[kGroup - 1] + sx;
