@@ -72,7 +72,7 @@ struct hmrm_scene {
 	bool bil_valid = false;
 	float *d_mipbuf_bil = nullptr; // the same over the 3x3-dilated table (bilinear quality mode)
 	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/16/64/256-cell windows every 2/8/32/128 cells
-	int32_t mip_w[4] = {0, 0, 0, 0}, mip_h[4] = {0, 0, 0, 0}, mip_off[4] = {0, 0, 0, 0};
+	int32_t mip_w[hmrm::kMipLevels] = {}, mip_h[hmrm::kMipLevels] = {}, mip_off[hmrm::kMipLevels] = {};
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	unsigned long long *d_counters = nullptr; // 8 x u64: steps, hits, capped, max key, 4 x traversal diagnostics
@@ -280,6 +280,8 @@ int prepare_frame_uncached(hmrm_scene *s, const hmrm_camera *cam, hipStream_t st
 		f->diag_mode = dg ? atoi(dg) : 0;
 	}
 	{
+		f->min_level = 0;
+		while (f->min_level < hmrm::kMipLevels - 1 && (2 << hmrm::mip_stride_shift(f->min_level)) < f->min_window) ++f->min_level;
 		const char *ml = getenv("HMRM_MIN_LEVEL"); // tools only: override the finest level used
 		if (ml && ml[0] >= '0' && ml[0] < '0' + hmrm::kMipLevels) f->min_level = ml[0] - '0';
 	}
@@ -386,7 +388,7 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 		HIP_TRY(hipMalloc((void **)&s->d_cmap, n * 4));
 		HIP_TRY(hipMalloc((void **)&s->d_thr, n * sizeof(double)));
 		for (int l = 0; l < hmrm::kMipLevels; ++l) {
-			const int stride = 1 << hmrm::kMipStrideShift[l]; // windows of 2*stride cells every stride cells
+			const int stride = 1 << hmrm::mip_stride_shift(l); // windows of 2*stride cells every stride cells
 			s->mip_w[l] = (map_w + stride - 1) / stride;
 			s->mip_h[l] = (map_h + stride - 1) / stride;
 			s->mip_off[l] = l == 0 ? 0 : s->mip_off[l - 1] + s->mip_w[l - 1] * s->mip_h[l - 1];

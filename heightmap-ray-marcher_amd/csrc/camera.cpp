@@ -145,7 +145,8 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min
 	// cell that is too few steps for a jump to pay for its bookkeeping (measured: C3 at 0.25
 	// cells/step wants level 0, C2/C4/C5 at 0.5 run 5-7 % faster without it).
 	const double cells_per_step = std::fabs(cam.step_dist / grid_width);
-	f->min_level = cells_per_step > 0.35 ? 1 : 0;
+	f->min_window = cells_per_step > 0.35 ? 16 : 4;
+	f->min_level = 0; // (api.cpp turns min_window into a level of the pyramid it built)
 }
 
 void estimate_row_costs(const DevFrame &f, const double *col_cos_ha, const double *col_sin_ha,

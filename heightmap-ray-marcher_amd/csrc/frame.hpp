@@ -45,15 +45,21 @@ struct DevFrame {
 	// at mip_off[l] and has ceil(map_w / (S/2)) windows per row.
 	const float *mipbuf;
 	const float *mipbuf_bil;     // the same pyramid over the 3x3-dilated table (bilinear quality mode)
-	int32_t mip_off[4];
+	int32_t mip_off[8];
 	int32_t diag_mode;           // tools only: what the instrumented kernel writes per pixel
 	int32_t sampling;            // 0 nearest cell (the reference), 1 bilinear quality mode
-	int32_t min_level;           // finest pyramid level worth an attempt (camera.cpp)
-	int32_t pad3_;
+	int32_t min_level;           // finest pyramid level worth an attempt (api.cpp, from min_window)
+	int32_t min_window;          // ... as a window size in cells (camera.cpp)
 };
 
-constexpr int kMipLevels = 4;
-constexpr int kMipStrideShift[4] = {1, 3, 5, 7}; // log2(S/2)
+// Window sizes S = 4 * 2^(kLevelStep*l) cells, placed every S/2 cells.  kLevelStep 2: S = 4, 16, 64, 256;
+// kLevelStep 1: S = 4, 8, 16, 32, 64, 128, 256.
+#ifndef HMRM_LEVEL_STEP
+#define HMRM_LEVEL_STEP 2
+#endif
+constexpr int kLevelStep = HMRM_LEVEL_STEP;
+constexpr int kMipLevels = kLevelStep == 2 ? 4 : 7;
+constexpr int mip_stride_shift(int l) { return 1 + kLevelStep * l; } // log2(S/2)
 
 // Which framebuffer rows a launch covers and where they land in the output.
 struct RowMap {

@@ -48,7 +48,7 @@ constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group
 #endif
 constexpr int kMinLeap = HMRM_MIN_LEAP; // a jump shorter than this is not worth its bookkeeping
 constexpr int kTopLevel = kMipLevels; // whole-map level (thr_max, no load)
-constexpr double kUpRatio = 4.0;      // see the level policy in k_render_fast
+constexpr double kUpRatio = kLevelStep == 2 ? 4.0 : 2.0; // see the level policy in k_render_fast
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
 __device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)(unsigned long long)__double_as_longlong(v); }
@@ -258,12 +258,14 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						const bool exact = ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
 						const bool top = lev == kTopLevel;
 						// window (ix,iy) of level lev: S = 2<<hs cells wide, every 1<<hs cells
-						const int hs = 2 * lev + 1;
+						const int hs = kLevelStep * lev + 1;
 						int ix = (gx >> hs) - offx, iy = (gy >> hs) - offy;
 						ix = ix < 0 ? 0 : ix;
 						iy = iy < 0 ? 0 : iy;
 						const int mw = (f.map_w + (1 << hs) - 1) >> hs; // windows per row (as built on the host)
-						const int loff = lev == 0 ? 0 : (lev == 1 ? f.mip_off[1] : (lev == 2 ? f.mip_off[2] : f.mip_off[3]));
+						int loff = 0;
+#pragma unroll
+						for (int l = 1; l < kMipLevels; ++l) loff = lev == l ? f.mip_off[l] : loff;
 						const float mf = (BILINEAR ? f.mipbuf_bil : f.mipbuf)[(top || !inb0) ? 0 : loff + iy * mw + ix];
 						const double m = top ? f.thr_max : (double)mf; // (thr_max also bounds every interpolated threshold)
 						const int wx0 = top ? 0 : ix << hs, wy0 = top ? 0 : iy << hs;
@@ -370,7 +372,12 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						const bool height_limited = inb0 && exact && (!above || z_bound);
 						const int coarser = lev >= kMipLevels - 1 ? kMipLevels - 1 : lev + 1;
 						const int minlev = f.min_level;
-						const int finer = top ? kMipLevels - 1 : (lev > minlev ? lev - 1 : minlev);
+#ifndef HMRM_DOWN
+#define HMRM_DOWN 1
+#endif
+						// a failed height test drops HMRM_DOWN levels, a height-limited jump one
+						const int drop = ok ? 1 : HMRM_DOWN;
+						const int finer = top ? kMipLevels - 1 : (lev - drop > minlev ? lev - drop : minlev);
 						const bool at_finest = lev == minlev;
 						// (selects, not branches: the three cases are mutually exclusive)
 						const bool crossed = ok && !z_bound;
@@ -584,19 +591,20 @@ __global__ __launch_bounds__(256) void k_build_mip0(const double *__restrict__ t
 	dst[i] = round_up_to_float(m);
 }
 
-// Level l+1 from level l: a window of 4S cells at cell 8H*i (H = stride of level l) is the union of
-// the level-l windows with indices 4i + {0,2,4,6} (each S cells wide, starting every 2H cells).
+// Level l+1 from level l (H = stride of level l, windows 2H wide): with F = 2^kLevelStep the window
+// of 2FH cells at cell FH*i is the union of the level-l windows with indices F*i + {0, 2, .., 2(F-1)}.
 __global__ __launch_bounds__(256) void k_build_mip_up(const float *__restrict__ src, int src_w, int src_h,
                                                       float *__restrict__ dst, int dst_w, int dst_h) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (int64_t)dst_w * dst_h) return;
 	const int ix = (int)(i % dst_w), iy = (int)(i / dst_w);
+	constexpr int F = 1 << kLevelStep;
 	float m = -__builtin_huge_valf();
-	for (int b = 0; b < 4; ++b) {
-		const int yy = 4 * iy + 2 * b;
+	for (int b = 0; b < F; ++b) {
+		const int yy = F * iy + 2 * b;
 		if (yy >= src_h) break;
-		for (int a = 0; a < 4; ++a) {
-			const int xx = 4 * ix + 2 * a;
+		for (int a = 0; a < F; ++a) {
+			const int xx = F * ix + 2 * a;
 			if (xx >= src_w) break;
 			const float v = src[(int64_t)yy * src_w + xx];
 			if (v > m) m = v;
