@@ -44,11 +44,14 @@ namespace {
 #endif
 constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group
 #ifndef HMRM_MIN_LEAP
-#define HMRM_MIN_LEAP 6
+#define HMRM_MIN_LEAP 2
 #endif
 constexpr int kMinLeap = HMRM_MIN_LEAP; // a jump shorter than this is not worth its bookkeeping
 constexpr int kTopLevel = kMipLevels; // whole-map level (thr_max, no load)
-constexpr double kUpRatio = kLevelStep == 2 ? 4.0 : 2.0; // see the level policy in k_render_fast
+#ifndef HMRM_UP_RATIO
+#define HMRM_UP_RATIO (kLevelStep == 2 ? 4.0 : 2.0)
+#endif
+constexpr double kUpRatio = HMRM_UP_RATIO; // see the level policy in k_render_fast
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
 __device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)(unsigned long long)__double_as_longlong(v); }
