@@ -274,38 +274,46 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						const int wx0 = top ? 0 : ix << hs, wy0 = top ? 0 : iy << hs;
 						const int wspan_x = top ? f.map_w : 2 << hs, wspan_y = top ? f.map_h : 2 << hs;
 						const bool above = z >= m;
-						// estimates of the steps left before each constraint bites; rdel is signed like
-						// the motion, so every quotient is >= 0.  Only estimates: verified below.
-						const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;  // x edge ahead
-						const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid; // y edge ahead
-						double room = (ax.lim - x) * ax.rdel;
-						room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
-						room = __builtin_fmin(room, (az.lim - z) * az.rdel);
-						const double room_b = room; // steps left inside the three binades
-						room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
-						room = __builtin_fmin(room, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
-						room = __builtin_fmin(room, (double)budget);
-						const double room_z = sz < 0.0 ? (m - z) * az.rdel : 0x1p40;
-						const bool z_bound = room_z < room;
-						room = __builtin_fmin(room, room_z);
-						room = __builtin_fmin(__builtin_fmax(room, 0.0), 0x1p30);
-						const int n = (int)(room * 0.998) - 1;
-						const bool can = inb0 && exact && above && n >= kMinLeap;
-						// landing point and its exact verification
-						const double nn = (double)n;
-						const double xn = x + nn * ax.delta, yn = y + nn * ay.delta, zn = z + nn * az.delta;
-						bool nearn = false;
-						double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
-						if (GWM == 2 && nearn) { qxn = xn / f.grid_width; qyn = -yn / f.grid_width; }
-						const int gxn = cvt_i32_sat(qxn), gyn = cvt_i32_sat(qyn);
-						const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim;
-						const bool ok = can && inbn && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
-						                (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
-						                axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
-						x = ok ? xn : x;
-						y = ok ? yn : y;
-						z = ok ? zn : z;
-						budget -= ok ? n : 0;
+						// Nothing below can succeed unless the ray is above this window's maximum: when no
+						// lane of the wave is, skip the estimate and the verification (the usual case in
+						// the last, nearly empty waves of a launch, which set its duration).
+						double room = 0.0, room_b = 0x1p40, room_z = 0.0;
+						bool z_bound = false, ok = false, can = false;
+						int n = 0;
+						if (__ballot(inb0 && exact && above) != 0ull) {
+							// estimates of the steps left before each constraint bites; rdel is signed like
+							// the motion, so every quotient is >= 0.  Only estimates: verified below.
+							const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;  // x edge ahead
+							const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid; // y edge ahead
+							room = (ax.lim - x) * ax.rdel;
+							room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
+							room = __builtin_fmin(room, (az.lim - z) * az.rdel);
+							room_b = room; // steps left inside the three binades
+							room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
+							room = __builtin_fmin(room, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
+							room = __builtin_fmin(room, (double)budget);
+							room_z = sz < 0.0 ? (m - z) * az.rdel : 0x1p40;
+							z_bound = room_z < room;
+							room = __builtin_fmin(room, room_z);
+							room = __builtin_fmin(__builtin_fmax(room, 0.0), 0x1p30);
+							n = (int)(room * 0.998) - 1;
+							can = inb0 && exact && above && n >= kMinLeap;
+							// landing point and its exact verification
+							const double nn = (double)n;
+							const double xn = x + nn * ax.delta, yn = y + nn * ay.delta, zn = z + nn * az.delta;
+							bool nearn = false;
+							double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
+							if (GWM == 2 && nearn) { qxn = xn / f.grid_width; qyn = -yn / f.grid_width; }
+							const int gxn = cvt_i32_sat(qxn), gyn = cvt_i32_sat(qyn);
+							const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim;
+							ok = can && inbn && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
+							     (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
+							     axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
+							x = ok ? xn : x;
+							y = ok ? yn : y;
+							z = ok ? zn : z;
+							budget -= ok ? n : 0;
+						}
 						if (STATS && f.diag_mode == 4) {
 							const bool ie = inb0 && exact;
 							dg_x0 += (ie && !above) ? 1u : 0u;
@@ -319,17 +327,6 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 							dg_x1 += (sl && lev == 1) ? 1u : 0u;
 							dg_x2 += (sl && lev == 2) ? 1u : 0u;
 							dg_x3 += (sl && lev >= 3) ? 1u : 0u;
-						}
-						if (STATS && f.diag_mode == 2 + 8) {
-							const bool sl = inb0 && exact && above && n < kMinLeap && !z_bound;
-							const double rbx = (ax.lim - x) * ax.rdel, rby = (ay.lim - y) * ay.rdel, rbz = (az.lim - z) * az.rdel;
-							const double rwx = sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40, rwy = sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40;
-							const double rb = __builtin_fmin(rbx, __builtin_fmin(rby, rbz));
-							const double rw = __builtin_fmin(rwx, rwy);
-							dg_x0 += (sl && rb < rw) ? 1u : 0u;       // binade-limited
-							dg_x1 += (sl && rb >= rw && rwx <= rwy) ? 1u : 0u; // window x edge
-							dg_x2 += (sl && rb >= rw && rwx > rwy) ? 1u : 0u;  // window y edge
-							dg_x3 += (sl && rbz <= rb && rb < rw) ? 1u : 0u;   // of the binade ones: z
 						}
 						if (STATS && f.diag_mode == 3 + 8) {
 							const bool bm = inb0 && exact && !above;

@@ -11,7 +11,7 @@ for name in sys.argv[1:] or ["C3", "C5"]:
     print(name, "attempts", st.leap_attempts, "leaps", st.leaps, "groups", st.groups, "leaped", st.leaped_steps, "steps", st.steps)
     for mode, labels in ((4, ("below max", "short z-bound", "short lateral", "verify failed")), (5, ("att L0", "att L1", "att L2", "att L3")),
                          (6, ("ok L0", "ok L1", "ok L2", "ok L3")), (7, ("steps L0", "steps L1", "steps L2", "steps L3")),
-                         (9, ("shortlat L0", "L1", "L2", "L3+")), (10, ("binade", "win x", "win y", "binade z")), (11, ("below L0", "L1", "L2", "L3")),
+                         (9, ("shortlat L0", "L1", "L2", "L3+")), (11, ("below L0", "L1", "L2", "L3")),
                          (12, ("wave iterations", "with attempt block", "with group block", "active lanes")),
                          (13, ("attempt lane slots", "useful", "group lane slots", "useful"))):
         os.environ["HMRM_DIAG_ITERS"] = str(mode)
