@@ -21,6 +21,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace hmrm {
 namespace {
@@ -614,16 +617,32 @@ bool load_image_file(const char *path, int req_comp, Image *out, std::string *er
 }
 
 // ---------------------------------------------------------------- deflate --
+// Same token stream as stb_image_write's stbi_zlib_compress (:895-1020), bit for bit, written
+// for speed: the recording path encodes one 4K frame per orbit step on host threads and is
+// bound by this function, not by the GPU.  What must be preserved: the hash, the 16384
+// buckets that keep between `quality` and 2*quality most recent starts (oldest half dropped
+// when full), the candidate order (oldest first, a later equal-length match replaces an
+// earlier one), the one-step lazy rule, and the fixed-Huffman coding.  What is free: how a
+// match length is counted (8 bytes at a time), rejecting a candidate from the one byte that
+// would have to extend the best match so far, table-driven codes, a 64-bit bit buffer.
 namespace {
 struct BitWriter {
-	std::vector<uint8_t> *out;
-	uint32_t buf = 0;
+	uint8_t *p = nullptr; // write cursor into a buffer the caller sized for the worst case
+	uint64_t buf = 0;
 	int count = 0;
-	void add(uint32_t code, int bits) {
-		buf |= code << count;
+	inline void add(uint32_t code, int bits) { // bits <= 25 here; flushed below 32
+		buf |= (uint64_t)code << count;
 		count += bits;
+		if (count >= 32) {
+			p[0] = (uint8_t)buf; p[1] = (uint8_t)(buf >> 8); p[2] = (uint8_t)(buf >> 16); p[3] = (uint8_t)(buf >> 24);
+			p += 4;
+			buf >>= 32;
+			count -= 32;
+		}
+	}
+	void flush_bytes() { // whole bytes only; count ends < 8
 		while (count >= 8) {
-			out->push_back((uint8_t)buf);
+			*p++ = (uint8_t)buf;
 			buf >>= 8;
 			count -= 8;
 		}
@@ -633,88 +652,170 @@ struct BitWriter {
 		while (bits--) { r = (r << 1) | (code & 1); code >>= 1; }
 		return r;
 	}
-	void huff(int n) { // fixed literal/length code of RFC 1951 3.2.6
-		if (n <= 143) add(rev(0x30 + n, 8), 8);
-		else if (n <= 255) add(rev(0x190 + n - 144, 9), 9);
-		else if (n <= 279) add(rev(n - 256, 7), 7);
-		else add(rev(0xc0 + n - 280, 8), 8);
+};
+
+struct DeflateTables {
+	uint16_t lit_code[288];
+	uint8_t lit_bits[288];
+	uint8_t len_sym[259];  // match length 3..258 -> index into lengthc
+	uint8_t dist_sym[32768]; // distance 1..32767 -> index into distc
+	uint16_t lengthc[30] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
+	                        35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 259};
+	uint8_t lengtheb[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+	uint16_t distc[31] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
+	                      257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 32768};
+	uint8_t disteb[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+	uint8_t dist_code5[30]; // the 5-bit distance symbol, bit-reversed
+	DeflateTables() {
+		for (int n = 0; n < 288; ++n) { // fixed literal/length code of RFC 1951 3.2.6
+			if (n <= 143) { lit_code[n] = (uint16_t)BitWriter::rev(0x30 + n, 8); lit_bits[n] = 8; }
+			else if (n <= 255) { lit_code[n] = (uint16_t)BitWriter::rev(0x190 + n - 144, 9); lit_bits[n] = 9; }
+			else if (n <= 279) { lit_code[n] = (uint16_t)BitWriter::rev(n - 256, 7); lit_bits[n] = 7; }
+			else { lit_code[n] = (uint16_t)BitWriter::rev(0xc0 + n - 280, 8); lit_bits[n] = 8; }
+		}
+		for (int len = 3; len <= 258; ++len) { // stb: for (j = 0; best > lengthc[j+1]-1; ++j);
+			int j = 0;
+			while (len > lengthc[j + 1] - 1) ++j;
+			len_sym[len] = (uint8_t)j;
+		}
+		dist_sym[0] = 0;
+		for (int d = 1; d < 32768; ++d) {
+			int j = 0;
+			while (d > distc[j + 1] - 1) ++j;
+			dist_sym[d] = (uint8_t)j;
+		}
+		for (int j = 0; j < 30; ++j) dist_code5[j] = (uint8_t)BitWriter::rev((uint32_t)j, 5);
 	}
 };
+const DeflateTables &deflate_tables() {
+	static const DeflateTables t;
+	return t;
+}
+
 inline uint32_t hash3(const uint8_t *d) {
 	uint32_t h = d[0] + (d[1] << 8) + (d[2] << 16);
 	h ^= h << 3; h += h >> 5; h ^= h << 4; h += h >> 17; h ^= h << 25; h += h >> 6;
 	return h;
 }
+// stbiw__zlib_countm: common prefix of a and b, at most min(limit, 258)
 inline int match_len(const uint8_t *a, const uint8_t *b, int limit) {
+	const int lim = limit < 258 ? limit : 258;
 	int i = 0;
-	for (; i < limit && i < 258; ++i) if (a[i] != b[i]) break;
+	while (i + 8 <= lim) {
+		uint64_t x, y;
+		memcpy(&x, a + i, 8);
+		memcpy(&y, b + i, 8);
+		if (x != y) return i + (__builtin_ctzll(x ^ y) >> 3); // (little endian: lowest differing byte)
+		i += 8;
+	}
+	while (i < lim && a[i] == b[i]) ++i;
 	return i;
 }
 } // namespace
 
-// Greedy-with-one-step-lazy LZ77 over 16384 hash buckets that keep the most
-// recent `quality`..2*quality starts, emitted as ONE fixed-Huffman block; falls
-// back to stored blocks when that is smaller (stb_image_write.h:895-1020).
 void zlib_deflate_stb(const uint8_t *data, int data_len, int quality, std::vector<uint8_t> *out) {
-	static const uint16_t lengthc[] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
-	                                   35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 259};
-	static const uint8_t lengtheb[] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2,
-	                                   2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-	static const uint16_t distc[] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
-	                                 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193,
-	                                 12289, 16385, 24577, 32768};
-	static const uint8_t disteb[] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6,
-	                                 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+	const DeflateTables &T = deflate_tables();
 	const int NB = 16384;
 	if (quality < 5) quality = 5;
-	out->clear();
-	out->push_back(0x78);
-	out->push_back(0x5e);
+	const int cap = 2 * quality;
+	// worst case of the fixed code: 9 bits per literal, plus header, end-of-block, padding, Adler-32
+	out->assign((size_t)data_len + (size_t)data_len / 8 + 64, 0);
+	(*out)[0] = 0x78;
+	(*out)[1] = 0x5e;
 	BitWriter bw;
-	bw.out = out;
+	bw.p = out->data() + 2;
 	bw.add(1, 1); // BFINAL
 	bw.add(1, 2); // BTYPE = fixed Huffman
-	std::vector<std::vector<int>> buckets((size_t)NB);
+	// bucket = up to `cap` (position, first three bytes) pairs, oldest first.  The three bytes
+	// let a scan drop hash collisions -- candidates that cannot reach the minimum match of 3 --
+	// without touching the data, four at a time.
+	const int stride = (cap + 3) & ~3;
+	std::vector<int> pos_tab((size_t)NB * (size_t)stride);
+	std::vector<uint32_t> tag_tab((size_t)NB * (size_t)stride, 0xffffffffu);
+	std::vector<uint8_t> fill((size_t)NB, 0);
+	auto first3 = [&](int at) { return (uint32_t)data[at] | ((uint32_t)data[at + 1] << 8) | ((uint32_t)data[at + 2] << 16); };
+	// indices j < n (ascending, as a bit mask) whose tag equals `want`
+	auto same3 = [&](const uint32_t *tags, int n, uint32_t want) -> uint32_t {
+		uint32_t m = 0;
+#if defined(__SSE2__)
+		const __m128i w = _mm_set1_epi32((int)want);
+		for (int g = 0; g < n; g += 4) {
+			const __m128i t = _mm_loadu_si128((const __m128i *)(tags + g));
+			m |= (uint32_t)_mm_movemask_ps(_mm_castsi128_ps(_mm_cmpeq_epi32(t, w))) << g;
+		}
+#else
+		for (int j = 0; j < n; ++j) m |= (uint32_t)(tags[j] == want) << j;
+#endif
+		return n >= 32 ? m : (m & ((1u << n) - 1u));
+	};
 
 	int i = 0;
 	while (i < data_len - 3) {
-		int h = (int)(hash3(data + i) & (NB - 1)), best = 3, bestloc = -1;
-		std::vector<int> &hl = buckets[(size_t)h];
-		for (size_t j = 0; j < hl.size(); ++j) {
-			if (hl[j] > i - 32768) {
-				int d = match_len(data + hl[j], data + i, data_len - i);
-				if (d >= best) { best = d; bestloc = hl[j]; }
+		if (i + 8 < data_len - 3) { // the buckets are 2 MB of random accesses: fetch the one a few bytes ahead
+			const size_t hp = (size_t)(hash3(data + i + 8) & (NB - 1)) * (size_t)stride;
+			__builtin_prefetch(&pos_tab[hp]);
+			__builtin_prefetch(&tag_tab[hp]);
+		}
+		const int h = (int)(hash3(data + i) & (NB - 1));
+		int best = 3, bestloc = -1;
+		int *hl = &pos_tab[(size_t)h * (size_t)stride];
+		uint32_t *ht = &tag_tab[(size_t)h * (size_t)stride];
+		int n = fill[(size_t)h];
+		const int limit = data_len - i;
+		const uint32_t cur3 = first3(i);
+		for (uint32_t m = same3(ht, n, cur3); m; m &= m - 1) {
+			const int c = hl[__builtin_ctz(m)];
+			if (c > i - 32768) {
+				// d >= best needs the first `best` bytes to agree: look at the last of them first
+				if (best - 1 < limit && data[c + best - 1] != data[i + best - 1]) continue;
+				const int d = match_len(data + c, data + i, limit);
+				if (d >= best) { best = d; bestloc = c; }
 			}
 		}
-		if ((int)hl.size() == 2 * quality) hl.erase(hl.begin(), hl.begin() + quality);
-		hl.push_back(i);
-		if (bestloc >= 0) {
-			int h2 = (int)(hash3(data + i + 1) & (NB - 1));
-			const std::vector<int> &hl2 = buckets[(size_t)h2];
-			for (size_t j = 0; j < hl2.size(); ++j) {
-				if (hl2[j] > i - 32767) {
-					int e = match_len(data + hl2[j], data + i + 1, data_len - i - 1);
-					if (e > best) { bestloc = -1; break; }
+		if (n == cap) { // keep the newer half
+			memmove(hl, hl + quality, sizeof(int) * (size_t)quality);
+			memmove(ht, ht + quality, sizeof(uint32_t) * (size_t)quality);
+			n = quality;
+		}
+		hl[n] = i;
+		ht[n] = cur3;
+		fill[(size_t)h] = (uint8_t)(n + 1);
+		if (bestloc >= 0) { // lazy: a longer match starting one byte later wins (then emit a literal)
+			const int h2 = (int)(hash3(data + i + 1) & (NB - 1));
+			const int *hl2 = &pos_tab[(size_t)h2 * (size_t)stride];
+			const int limit2 = data_len - i - 1;
+			if (best < limit2 && best < 258) { // else no e > best exists
+				for (uint32_t m = same3(&tag_tab[(size_t)h2 * (size_t)stride], fill[(size_t)h2], first3(i + 1)); m; m &= m - 1) {
+					const int c = hl2[__builtin_ctz(m)];
+					if (c > i - 32767) {
+						// e > best needs best+1 agreeing bytes
+						if (data[c + best] != data[i + 1 + best]) continue;
+						const int e = match_len(data + c, data + i + 1, limit2);
+						if (e > best) { bestloc = -1; break; }
+					}
 				}
 			}
 		}
 		if (bestloc >= 0) {
-			int d = i - bestloc, j;
-			for (j = 0; best > lengthc[j + 1] - 1; ++j) {}
-			bw.huff(j + 257);
-			if (lengtheb[j]) bw.add((uint32_t)(best - lengthc[j]), lengtheb[j]);
-			for (j = 0; d > distc[j + 1] - 1; ++j) {}
-			bw.add(BitWriter::rev((uint32_t)j, 5), 5);
-			if (disteb[j]) bw.add((uint32_t)(d - distc[j]), disteb[j]);
+			const int d = i - bestloc;
+			const int j = T.len_sym[best];
+			bw.add(T.lit_code[j + 257], T.lit_bits[j + 257]);
+			if (T.lengtheb[j]) bw.add((uint32_t)(best - T.lengthc[j]), T.lengtheb[j]);
+			const int k = T.dist_sym[d];
+			bw.add(T.dist_code5[k], 5);
+			if (T.disteb[k]) bw.add((uint32_t)(d - T.distc[k]), T.disteb[k]);
 			i += best;
 		} else {
-			bw.huff(data[i]);
+			bw.add(T.lit_code[data[i]], T.lit_bits[data[i]]);
 			++i;
 		}
 	}
-	for (; i < data_len; ++i) bw.huff(data[i]);
-	bw.huff(256);
-	while (bw.count) bw.add(0, 1);
+	for (; i < data_len; ++i) bw.add(T.lit_code[data[i]], T.lit_bits[data[i]]);
+	bw.add(T.lit_code[256], T.lit_bits[256]);
+	bw.flush_bytes();
+	if (bw.count) bw.add(0, 8 - bw.count); // pad the last byte with zero bits
+	bw.flush_bytes();
+	out->resize((size_t)(bw.p - out->data()));
 
 	if ((long)out->size() > (long)data_len + 2 + ((data_len + 32766) / 32767) * 5) {
 		out->resize(2);
@@ -730,12 +831,17 @@ void zlib_deflate_stb(const uint8_t *data, int data_len, int quality, std::vecto
 			j += blocklen;
 		}
 	}
+	// Adler-32, reduced every 5552 bytes (the largest run that cannot overflow 32 bits)
 	uint32_t s1 = 1, s2 = 0;
-	for (int j = 0; j < data_len; ++j) {
-		s1 += data[j];
-		if (s1 >= 65521) s1 -= 65521;
-		s2 += s1;
-		if (s2 >= 65521) s2 -= 65521;
+	for (int j = 0; j < data_len;) {
+		const int run = data_len - j < 5552 ? data_len - j : 5552;
+		for (int k = 0; k < run; ++k) {
+			s1 += data[j + k];
+			s2 += s1;
+		}
+		s1 %= 65521;
+		s2 %= 65521;
+		j += run;
 	}
 	out->push_back((uint8_t)(s2 >> 8));
 	out->push_back((uint8_t)s2);
@@ -774,28 +880,82 @@ void put_chunk(std::vector<uint8_t> *o, const char tag[4], const uint8_t *data, 
 	put32(o, crc32_png(o->data() + start, n + 4));
 }
 
-// One filtered row.  kind: 0 none, 1 sub, 2 up, 3 average, 4 paeth; on the first
-// row "up" degenerates to none, "average" to left>>1 and "paeth" to sub.
-void filter_row(const uint8_t *row, const uint8_t *prev, int row_bytes, int n, int kind, int8_t *dst) {
+// Row filters as stb applies them (stb_image_write.h:1073-1126).  kind: 0 none, 1 sub, 2 up,
+// 3 average, 4 paeth; on the first row "up" degenerates to none, "average" to left>>1 and
+// "paeth" to sub.  `n` = bytes per pixel.  The encoder needs, per row, the sum of |int8(v)|
+// of every filter (first minimum wins) and then the bytes of the winner only: one pass
+// for the five sums, one pass to write.
+inline int abs_i8(int v) {
+	const int s = (int)(int8_t)v;
+	return s < 0 ? -s : s;
+}
+void filter_sums(const uint8_t *row, const uint8_t *prev, int row_bytes, int n, int est[5]) {
+	int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+	if (prev) {
+		for (int i = 0; i < n && i < row_bytes; ++i) { // no left neighbour: left = ul = 0
+			const int v = row[i], up = prev[i];
+			e0 += abs_i8(v);
+			e1 += abs_i8(v);
+			e2 += abs_i8(v - up);
+			e3 += abs_i8(v - (up >> 1));
+			e4 += abs_i8(v - paeth_predict(0, up, 0));
+		}
+		for (int i = n; i < row_bytes; ++i) {
+			const int v = row[i], left = row[i - n], up = prev[i], ul = prev[i - n];
+			e0 += abs_i8(v);
+			e1 += abs_i8(v - left);
+			e2 += abs_i8(v - up);
+			e3 += abs_i8(v - ((left + up) >> 1));
+			e4 += abs_i8(v - paeth_predict(left, up, ul));
+		}
+	} else {
+		for (int i = 0; i < n && i < row_bytes; ++i) {
+			const int a = abs_i8(row[i]);
+			e0 += a; e1 += a; e2 += a; e3 += a; e4 += a;
+		}
+		for (int i = n; i < row_bytes; ++i) {
+			const int v = row[i], left = row[i - n];
+			e0 += abs_i8(v);
+			e1 += abs_i8(v - left);
+			e2 += abs_i8(v);
+			e3 += abs_i8(v - (left >> 1));
+			e4 += abs_i8(v - left);
+		}
+	}
+	est[0] = e0; est[1] = e1; est[2] = e2; est[3] = e3; est[4] = e4;
+}
+void filter_row(const uint8_t *row, const uint8_t *prev, int row_bytes, int n, int kind, uint8_t *dst) {
 	if (!prev) {
 		static const int first_row[5] = {0, 1, 0, 5, 6};
 		kind = first_row[kind];
 	}
-	for (int i = 0; i < row_bytes; ++i) {
-		int left = i >= n ? row[i - n] : 0;
-		int up = prev ? prev[i] : 0;
-		int ul = (prev && i >= n) ? prev[i - n] : 0;
-		int v = row[i];
-		switch (kind) {
-		case 1: v -= left; break;
-		case 2: v -= up; break;
-		case 3: v -= (left + up) >> 1; break;
-		case 4: v -= paeth_predict(left, up, ul); break;
-		case 5: v -= left >> 1; break;
-		case 6: v -= left; break;
-		default: break;
-		}
-		dst[i] = (int8_t)v;
+	const int head = n < row_bytes ? n : row_bytes;
+	switch (kind) {
+	case 0:
+		memcpy(dst, row, (size_t)row_bytes);
+		break;
+	case 1:
+	case 6:
+		for (int i = 0; i < head; ++i) dst[i] = row[i];
+		for (int i = n; i < row_bytes; ++i) dst[i] = (uint8_t)(row[i] - row[i - n]);
+		break;
+	case 2:
+		for (int i = 0; i < row_bytes; ++i) dst[i] = (uint8_t)(row[i] - prev[i]);
+		break;
+	case 3:
+		for (int i = 0; i < head; ++i) dst[i] = (uint8_t)(row[i] - (prev[i] >> 1));
+		for (int i = n; i < row_bytes; ++i) dst[i] = (uint8_t)(row[i] - ((row[i - n] + prev[i]) >> 1));
+		break;
+	case 4:
+		for (int i = 0; i < head; ++i) dst[i] = (uint8_t)(row[i] - paeth_predict(0, prev[i], 0));
+		for (int i = n; i < row_bytes; ++i) dst[i] = (uint8_t)(row[i] - paeth_predict(row[i - n], prev[i], prev[i - n]));
+		break;
+	case 5:
+		for (int i = 0; i < head; ++i) dst[i] = row[i];
+		for (int i = n; i < row_bytes; ++i) dst[i] = (uint8_t)(row[i] - (row[i - n] >> 1));
+		break;
+	default:
+		break;
 	}
 }
 } // namespace
@@ -807,20 +967,17 @@ bool encode_png(int32_t w, int32_t h, int32_t comp, const uint8_t *data, size_t 
 	const int row_bytes = w * comp;
 	if ((long long)(row_bytes + 1) * h > 0x7fffffffLL) return false; // stb's int arithmetic limit
 	std::vector<uint8_t> filt((size_t)(row_bytes + 1) * h);
-	std::vector<int8_t> line((size_t)row_bytes), best_line((size_t)row_bytes);
 	for (int y = 0; y < h; ++y) {
 		const uint8_t *row = data + stride_bytes * (size_t)y;
 		const uint8_t *prev = y ? row - stride_bytes : nullptr;
+		int est[5];
+		filter_sums(row, prev, row_bytes, comp, est);
 		int best = 0, best_val = 0x7fffffff;
-		for (int ft = 0; ft < 5; ++ft) {
-			filter_row(row, prev, row_bytes, comp, ft, line.data());
-			int est = 0;
-			for (int i = 0; i < row_bytes; ++i) est += abs((int)line[i]);
-			if (est < best_val) { best_val = est; best = ft; best_line.swap(line); }
-		}
+		for (int ft = 0; ft < 5; ++ft)
+			if (est[ft] < best_val) { best_val = est[ft]; best = ft; }
 		uint8_t *dst = &filt[(size_t)(row_bytes + 1) * y];
 		dst[0] = (uint8_t)best;
-		memcpy(dst + 1, best_line.data(), (size_t)row_bytes);
+		filter_row(row, prev, row_bytes, comp, best, dst + 1);
 	}
 	std::vector<uint8_t> z;
 	zlib_deflate_stb(filt.data(), (int)filt.size(), 8, &z);

@@ -192,6 +192,13 @@ def encode_test_images():
     heights = oracle.update_heightmap(rgb, params)
     fb, *_ = oracle.render(oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0]), heights, cmap)
     imgs["oracle_frame"] = fb
+    # match-finder stress: a period longer than the 32 KiB window, overflowing hash buckets, maximal runs
+    r2 = np.random.RandomState(7)
+    imgs["long_period"] = np.tile(r2.randint(0, 256, size=(1, 10000, 4)).astype(np.uint8), (6, 1, 1))
+    imgs["runs"] = np.repeat(r2.randint(0, 256, size=(120, 40, 3)).astype(np.uint8), 30, axis=1)
+    imgs["noisy_ramp"] = ((np.arange(640)[None, :, None] // 3 + np.arange(360)[:, None, None] // 2
+                           + r2.randint(0, 16, size=(360, 640, 4))) & 255).astype(np.uint8)
+    imgs["zeros"] = np.zeros((300, 400, 4), np.uint8)
     return imgs
 
 

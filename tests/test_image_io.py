@@ -189,6 +189,21 @@ def test_png_encode_matches_reference_stb_live(hmrm, stb_ref):
             else:
                 img = np.full((h, w, c), 200, dtype=np.uint8)
             assert hmrm.png_encode(img) == stb_ref.write_png(img), (h, w, c, kind)
+    # shapes that stress the match finder: > 32 KiB periods (window edge), buckets that overflow and drop
+    # their older half, runs of maximal matches (258), a stream that falls back to stored blocks
+    extra = {
+        "long period": np.tile(rng.randint(0, 256, size=(1, 10000, 4)).astype(np.uint8), (6, 1, 1)),
+        "period 32768": np.tile(rng.randint(0, 256, size=(1, 8192, 4)).astype(np.uint8), (4, 1, 1))[:, :8192],
+        "zeros": np.zeros((300, 400, 4), np.uint8),
+        "runs": np.repeat(rng.randint(0, 256, size=(120, 40, 3)).astype(np.uint8), 30, axis=1),
+        "few symbols": (rng.randint(0, 3, size=(257, 501, 2)) * 100).astype(np.uint8),
+        "noisy ramp": ((np.arange(640)[None, :, None] // 3 + np.arange(360)[:, None, None] // 2
+                        + rng.randint(0, 16, size=(360, 640, 4))) & 255).astype(np.uint8),
+        "one row": rng.randint(0, 2, size=(1, 5000, 3)).astype(np.uint8),
+        "one column": rng.randint(0, 256, size=(3000, 1, 1)).astype(np.uint8),
+    }
+    for name, img in extra.items():
+        assert hmrm.png_encode(np.ascontiguousarray(img)) == stb_ref.write_png(np.ascontiguousarray(img)), name
 
 
 def test_png_roundtrip_and_files(hmrm, tmp_path):
