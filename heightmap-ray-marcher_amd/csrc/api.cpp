@@ -219,11 +219,14 @@ int prepare_frame(hmrm_scene *s, const hmrm_camera *cam, hipStream_t stream, hmr
 		s->cache_valid = true;
 	}
 	*f = s->cache_frame;
+	// per-call settings from the environment (not part of the cached record)
 	f->step_cap = default_step_cap();
-	{
-		const char *dg = getenv("HMRM_DIAG_ITERS");
-		f->diag_mode = dg ? atoi(dg) : 0;
-	}
+	// tools only: HMRM_DIAG_ITERS=n makes the instrumented kernel report diagnostics instead of step
+	// counts (render_fast.hip), HMRM_MIN_LEVEL=l overrides the finest pyramid level attempted
+	const char *dg = getenv("HMRM_DIAG_ITERS");
+	f->diag_mode = dg ? atoi(dg) : 0;
+	const char *ml = getenv("HMRM_MIN_LEVEL");
+	if (ml && ml[0] >= '0' && ml[0] < '0' + hmrm::kMipLevels) f->min_level = ml[0] - '0';
 	return HMRM_OK;
 }
 
@@ -273,23 +276,13 @@ int prepare_frame_uncached(hmrm_scene *s, const hmrm_camera *cam, hipStream_t st
 	}
 	f->thr_max = cam->sampling == HMRM_BILINEAR ? s->thr_max_bil : s->thr_max;
 	f->step_cap = default_step_cap();
-	// diagnostic: HMRM_DIAG_ITERS=1 makes the instrumented kernel report (attempts<<16 | groups)
-	// per pixel instead of the step count (tools/ only)
-	{
-		const char *dg = getenv("HMRM_DIAG_ITERS");
-		f->diag_mode = dg ? atoi(dg) : 0;
-	}
-	{
-		f->min_level = 0;
-		while (f->min_level < hmrm::kMipLevels - 1 && (2 << hmrm::mip_stride_shift(f->min_level)) < f->min_window) ++f->min_level;
-		const char *ml = getenv("HMRM_MIN_LEVEL"); // tools only: override the finest level used
-		if (ml && ml[0] >= '0' && ml[0] < '0' + hmrm::kMipLevels) f->min_level = ml[0] - '0';
-	}
-	for (int l = 0; l < hmrm::kMipLevels; ++l) {
-		f->mipbuf = s->d_mipbuf;
-		f->mipbuf_bil = s->d_mipbuf_bil;
-		f->mip_off[l] = s->mip_off[l];
-	}
+	// the finest level whose windows have at least min_window cells (camera.cpp's hint)
+	f->min_level = 0;
+	while (f->min_level < hmrm::kMipLevels - 1 && (2 << hmrm::mip_stride_shift(f->min_level)) < f->min_window)
+		++f->min_level;
+	f->mipbuf = s->d_mipbuf;
+	f->mipbuf_bil = s->d_mipbuf_bil;
+	for (int l = 0; l < hmrm::kMipLevels; ++l) f->mip_off[l] = s->mip_off[l];
 	return HMRM_OK;
 }
 
