@@ -140,12 +140,16 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min
 	f->inv_grid_width = 1.0 / grid_width;
 	f->grid_mode = grid_width == 1.0 ? 0 : (f->grid_pow2 ? 1 : 2);
 
-	// Scheduling hint only (never changes a pixel): the finest pyramid level has 4-cell windows
+	// Scheduling hints only (never change a pixel).  The finest pyramid level has 4-cell windows
 	// placed every 2 cells, i.e. 2..4 cells of room; with steps longer than about a third of a
-	// cell that is too few steps for a jump to pay for its bookkeeping (measured: C3 at 0.25
-	// cells/step wants level 0, C2/C4/C5 at 0.5 run 5-7 % faster without it).
+	// cell that is too few steps for a jump to pay for its bookkeeping, and the 16-cell level is
+	// the finest one used (measured: C3 at 0.25 cells/step wants the 4-cell level, C2/C4/C5 at 0.5
+	// run 5-7 % faster without it).  After a refused attempt at the finest level the ray marches
+	// real steps before it looks again: one group when windows are 4 cells (16 steps) wide, four
+	// when they are 16 cells (32 steps) wide (2-4 % either way).
 	const double cells_per_step = std::fabs(cam.step_dist / grid_width);
 	f->min_window = cells_per_step > 0.35 ? 16 : 4;
+	f->finest_pause = cells_per_step > 0.35 ? 3 : 0;
 	f->min_level = 0; // (api.cpp turns min_window into a level of the pyramid it built)
 }
 

@@ -50,6 +50,8 @@ struct DevFrame {
 	int32_t sampling;            // 0 nearest cell (the reference), 1 bilinear quality mode
 	int32_t min_level;           // finest pyramid level worth an attempt (api.cpp, from min_window)
 	int32_t min_window;          // ... as a window size in cells (camera.cpp)
+	int32_t finest_pause;        // extra groups marched after a refused attempt at that level (camera.cpp)
+	int32_t pad4_;
 };
 
 // Window sizes S = 4 * 2^(kLevelStep*l) cells, placed every S/2 cells.  kLevelStep 2: S = 4, 16, 64, 256;

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						//   jump ended at a binade boundary   -> same level, and march a group first
 						//   height bound was the limit        -> finer; without a jump retry at once (the
 						//     (z < max, or z-room smallest)      level strictly decreases); at the finest
-						//                                        level march two groups before looking again
+						//                                        level march 1 + finest_pause groups first
 						//   no lateral/binade room, not exact -> coarser (a bigger window has more room),
 						//                                        growing pause while attempts keep failing
 						const bool binade_bound = room_b <= room;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						const int fails_before = fails;
 						lev = hl ? finer : (go_up ? coarser : lev);
 						fails = (crossed || (hl && ok)) ? 0 : (other ? fails + 1 : fails);
-						cooldown = hl ? ((!ok && at_finest) ? 1 : 0) : (other ? (fails_before < 3 ? fails_before : 3) : 0);
+						cooldown = hl ? ((!ok && at_finest) ? f.finest_pause : 0) : (other ? (fails_before < 3 ? fails_before : 3) : 0);
 						skip_group = hl && !ok && !at_finest; // retry one level down without marching
 						// after a jump look at the next window straight away -- unless the jump stopped at a
 						// binade boundary: only real steps cross it, another attempt here would just fail
