@@ -115,6 +115,51 @@ def test_bmp_tga_decode_matches_reference_stb(hmrm, stb_ref):
             hmrm.image_load_memory(blob, 3)
 
 
+def test_gif_psd_pic_hdr_decode_matches_reference_stb(hmrm, stb_ref):
+    """The remaining stbi_load formats (GIF first frame, PSD, Softimage PIC, Radiance HDR -> 8 bit): golden
+    vectors from the reference's stb for hand-built files (tests/more_format_fixtures.py) + live comparison."""
+    data = np.load(os.path.join(GOLDEN, "more_formats.npz"))
+    names = _names(data)
+    assert {n.split(".")[0] for n in names} == {"gif", "psd", "pic", "hdr"} and len(names) >= 32
+    for name in names:
+        blob = data[name + "/bytes"].tobytes()
+        for req in range(5):
+            arr, n = hmrm.image_load_memory(blob, req)
+            assert n == int(data[f"{name}/n{req}"][0]), (name, req)
+            assert arr.shape == data[f"{name}/req{req}"].shape and np.array_equal(arr, data[f"{name}/req{req}"]), (name, req)
+    if stb_ref is None:
+        return
+    # the fixtures are still what the golden file holds, and every cut of them is refused or decoded alike
+    import more_format_fixtures
+    files = more_format_fixtures.fixture_files()
+    rng = np.random.RandomState(11)
+    agree = refused = 0
+    for name, blob in files.items():
+        assert blob == data[name.replace("/", ".") + "/bytes"].tobytes(), name
+        for cut in sorted(set(rng.randint(1, len(blob), size=12).tolist())):
+            part = blob[:cut]
+            if name.startswith("hdr/"):
+                # stb v2.27 loops forever on a zero run count (what a cut HDR scanline reads as) and converts
+                # an unset stack buffer after a short flat read: only check that this decoder returns
+                try:
+                    hmrm.image_load_memory(part, 4)
+                except hmrm.HmrmError:
+                    pass
+                continue
+            exp, n = stb_ref.load(part, 4)
+            try:
+                arr, n2 = hmrm.image_load_memory(part, 4)
+            except hmrm.HmrmError:
+                arr = None
+            assert (exp is None) == (arr is None), (name, cut)
+            if exp is not None:
+                assert n == n2 and np.array_equal(arr, exp), (name, cut)
+                agree += 1
+            else:
+                refused += 1
+    assert agree > 30 and refused > 30
+
+
 def test_jpeg_heightmap_through_config(hmrm, tmp_path):
     """`heightmap x.jpg` / `colormap x.jpg` as in the reference's sample_config.txt."""
     data = np.load(os.path.join(GOLDEN, "jpeg_decode.npz"))
