@@ -405,6 +405,28 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						dg_x3 += (unsigned)__popcll(act);
 					}
 				}
+				if (STATS && f.diag_mode == 14) { // attempt iterations by the share of active lanes that attempt
+					const unsigned long long act = __ballot(true);
+					const unsigned long long att = __ballot(LEAP && dg_attempted);
+					if (att && (int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
+						const int na = __popcll(att), nact = __popcll(act);
+						dg_x0 += (8 * na < nact) ? 1u : 0u;
+						dg_x1 += (8 * na >= nact && 4 * na < nact) ? 1u : 0u;
+						dg_x2 += (4 * na >= nact && 2 * na < nact) ? 1u : 0u;
+						dg_x3 += (2 * na >= nact) ? 1u : 0u;
+					}
+				}
+				if (STATS && f.diag_mode == 15) { // group iterations by the share of active lanes that march
+					const unsigned long long act = __ballot(true);
+					const unsigned long long grp = __ballot(!skip_group);
+					if (grp && (int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
+						const int ng = __popcll(grp), nact = __popcll(act);
+						dg_x0 += (8 * ng < nact) ? 1u : 0u;
+						dg_x1 += (8 * ng >= nact && 4 * ng < nact) ? 1u : 0u;
+						dg_x2 += (4 * ng >= nact && 2 * ng < nact) ? 1u : 0u;
+						dg_x3 += (2 * ng >= nact) ? 1u : 0u;
+					}
+				}
 				if (STATS && f.diag_mode == 13) { // lanes doing useful work in each block
 					const unsigned long long att = __ballot(LEAP && dg_attempted);
 					const unsigned long long grp = __ballot(!skip_group);

@@ -13,7 +13,9 @@ for name in sys.argv[1:] or ["C3", "C5"]:
                          (6, ("ok L0", "ok L1", "ok L2", "ok L3")), (7, ("steps L0", "steps L1", "steps L2", "steps L3")),
                          (9, ("shortlat L0", "L1", "L2", "L3+")), (11, ("below L0", "L1", "L2", "L3")),
                          (12, ("wave iterations", "with attempt block", "with group block", "active lanes")),
-                         (13, ("attempt lane slots", "useful", "group lane slots", "useful"))):
+                         (13, ("attempt lane slots", "attempt useful", "group lane slots", "group useful")),
+                         (14, ("attempt iters share<1/8", "1/8..1/4", "1/4..1/2", ">=1/2")),
+                         (15, ("group iters share<1/8", "1/8..1/4", "1/4..1/2", ">=1/2"))):
         os.environ["HMRM_DIAG_ITERS"] = str(mode)
         cam.bg_r = mode  # defeat the frame cache
         _, s2, *_ = scene.render_stats(cam)
