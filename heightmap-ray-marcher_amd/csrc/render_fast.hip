@@ -272,7 +272,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						const float mf = (BILINEAR ? f.mipbuf_bil : f.mipbuf)[(top || !inb0) ? 0 : loff + iy * mw + ix];
 						const double m = top ? f.thr_max : (double)mf; // (thr_max also bounds every interpolated threshold)
 						const int wx0 = top ? 0 : ix << hs, wy0 = top ? 0 : iy << hs;
-						const int wspan_x = top ? f.map_w : 2 << hs, wspan_y = top ? f.map_h : 2 << hs;
+						// (the last windows of a row / column hang over the map's edge: the usable span ends at the edge)
+						const int wspan_x = top ? f.map_w : min(2 << hs, f.map_w - wx0), wspan_y = top ? f.map_h : min(2 << hs, f.map_h - wy0);
 						const bool above = z >= m;
 						// Nothing below can succeed unless the ray is above this window's maximum: when no
 						// lane of the wave is, skip the estimate and the verification (the usual case in
@@ -309,6 +310,13 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 							ok = can && inbn && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
 							     (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
 							     axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
+							if (STATS && f.diag_mode == 10 && can && !ok) { // which landing test refused the jump
+								const bool win = (unsigned)(gxn - wx0) < (unsigned)wspan_x && (unsigned)(gyn - wy0) < (unsigned)wspan_y;
+								dg_x0 += !inbn ? 1u : 0u;
+								dg_x1 += (inbn && !win) ? 1u : 0u;
+								dg_x2 += (inbn && win && !(zn >= m)) ? 1u : 0u;
+								dg_x3 += (inbn && win && zn >= m) ? 1u : 0u; // binade / boundary tests
+							}
 							x = ok ? xn : x;
 							y = ok ? yn : y;
 							z = ok ? zn : z;
