@@ -225,7 +225,18 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 			const bool entry_nan = x != x || y != y;
 
 			// leap state
-			int lev = kTopLevel; // rays enter the box above everything: first try the whole-map bound
+			// First level to look at: a finer window has a lower maximum, so the finest level whose
+			// windows still leave the ray lateral room for its whole descent to the box floor is the
+			// best one (steep rays: the finest level at once, instead of walking down from the top);
+			// oblique rays start with the whole-map bound.  Performance only.
+			int lev = kTopLevel;
+			if (sz < 0.0) {
+				const double descent = (z - f.c0[2]) * __builtin_amdgcn_rcp(-sz); // steps down to min_height
+				const double lateral = descent * __builtin_fmax(__builtin_fabs(sx), __builtin_fabs(sy)) * (GWM == 0 ? 1.0 : f.inv_grid_width);
+#pragma unroll
+				for (int l = kMipLevels - 1; l >= 0; --l) // windows every 1 << hs cells: at least that much room ahead
+					lev = (l >= f.min_level && lateral <= (double)(1 << (kLevelStep * l + 1))) ? l : lev;
+			}
 			int cooldown = 0, fails = 0;
 			Axis ax, ay, az;
 			ax.key = ay.key = az.key = 0xfffffffeu; // never matches: forces the first refresh
