@@ -14,6 +14,9 @@ for name in sys.argv[1:] or ["C3", "C5"]:
         cam.pos[0], cam.pos[1], cam.pos[2] = cam.pos[0] * gw, cam.pos[1] * gw, cam.pos[2] * gw
         cam.step_dist = wl.step_dist * gw
         cam.ortho_width = cam.ortho_width * gw
+    if os.environ.get("HMRM_DIAG_CAM") == "down":  # perspective, 60 degrees, looking down at 140: every ray hits
+        cam.projection, cam.hfov, cam.vang = 1, hm.degrees_to_rads(60), hm.degrees_to_rads(140.0)
+        cam.pos[0], cam.pos[1], cam.pos[2] = 1000.0 * gw, -1000.0 * gw, 1500.0 * gw
     scene = hm.Scene(rgb, cmap, params)
     _, st, *_ = scene.render_stats(cam)
     print(name, "attempts", st.leap_attempts, "leaps", st.leaps, "groups", st.groups, "leaped", st.leaped_steps, "steps", st.steps)
