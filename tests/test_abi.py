@@ -89,3 +89,15 @@ def test_argument_validation_without_gpu(hmrm):
     assert lib.hmrm_image_load(None, 3, None, None, None, None) == hmrm.HMRM_E_ARG
     out = hmrm.orbit_camera(cam, 0.0, 0.0, 10.0, 0.0, 0, 0)   # frames = 0 must not divide by zero
     assert out.pos[0] == -10.0 and out.pos[1] == 0.0
+
+
+def test_scripts_compile():
+    """tools/ and the stand-alone fuzzers under tests/ run only on the GPU box: at least keep them syntactically valid."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "tests", "deep_fuzz*.py"))
+                   + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")])
+    assert len(files) >= 15
+    for f in files:
+        py_compile.compile(f, doraise=True)
