@@ -75,7 +75,13 @@ def cpu_baseline(hmrm, wl, rgb, cmap, params, cam, target_s=15.0):
         _, steps, _, _, _ = oracle.render(cfg, heights, cmap, row_stride=stride)
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
+    # the reference's own makefile builds without -O: the same port at -O0 on a quarter of the sample
+    stride0 = max(1, stride * 4)
+    t0 = time.perf_counter()
+    _, steps0, _, _, _ = oracle.render(cfg, heights, cmap, row_stride=stride0, opt="O0")
+    dt0 = max(time.perf_counter() - t0, 1e-9)
     return {"value": steps / dt, "unit": "ray-steps/s", "cores": cores, "kind": "port",
+            "value_at_reference_flags_O0": steps0 / dt0,
             "mrays_per_s": nrows * cam.width / dt / 1e6,
             "sample": f"every {stride}th row of the {cam.width}x{cam.height} frame ({nrows} rows, "
                       f"{steps} ray-steps, {dt:.2f} s wall x {cores} threads, median of {reps}; "
