@@ -113,7 +113,6 @@ int choose_tile_rot(const hmrm_scene *s, const hmrm::DevFrame &f, const hmrm::Ro
 	if ((ord && ord[0] == '0') || rows.band_rows > 0 || s->row_cost.empty()) return 0;
 	int tile_w = 1, tile_h = 1;
 	hmrm::render_tile_shape(&tile_w, &tile_h);
-	const int tiles_x = (f.screen_w + tile_w - 1) / tile_w;
 	const int tiles_y = (rows.local_rows + tile_h - 1) / tile_h;
 	if (tiles_y <= 1) return 0;
 	auto tile_cost = [&](int t) {
@@ -127,7 +126,7 @@ int choose_tile_rot(const hmrm_scene *s, const hmrm::DevFrame &f, const hmrm::Ro
 	for (int t = 0; t < tiles_y; ++t) top = std::max(top, tile_cost(t));
 	if (!(top > 0.0f)) return 0;
 	for (int t = 0; t < tiles_y; ++t)
-		if (tile_cost(t) >= 0.1f * top) return t * tiles_x;
+		if (tile_cost(t) >= 0.1f * top) return t;
 	return 0;
 }
 

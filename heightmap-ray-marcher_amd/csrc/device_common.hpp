@@ -178,12 +178,16 @@ struct PixelId {
 	int px, py, lrow;
 	bool live;
 };
-__device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap &rows, int tiles_x) {
-	// launch order rotated so that the costliest tile rows start first (RowMap::tile_rot)
-	unsigned t = blockIdx.x + (unsigned)rows.tile_rot;
-	if (t >= gridDim.x) t -= gridDim.x;
-	const int tile = (int)t;
-	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+__device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap &rows, int tiles_y) {
+	// Grid of tiles: x = tile column (fastest, so workgroups still start row by row), y (+ z for
+	// frames taller than 32768 tile rows) = tile row; the rows are rotated so that the costliest
+	// ones start first (RowMap::tile_rot, in tile rows).  No integer division per wave.
+	const int tile_x = (int)blockIdx.x;
+	unsigned ty = blockIdx.z * 32768u + blockIdx.y;
+	const bool row_exists = ty < (unsigned)tiles_y; // (the last z-slab may be partly empty)
+	ty += (unsigned)rows.tile_rot;
+	if (ty >= (unsigned)tiles_y) ty -= (unsigned)tiles_y;
+	const int tile_y = (int)ty;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	PixelId p;
 	p.px = tile_x * kTileW + (wave % kWavesX) * kWaveW + (lane % kWaveW);
@@ -194,7 +198,7 @@ __device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap
 	} else {
 		p.py = rows.row_begin + p.lrow;
 	}
-	p.live = p.px < f.screen_w && p.lrow < rows.local_rows && p.py < f.screen_h;
+	p.live = row_exists && p.px < f.screen_w && p.lrow < rows.local_rows && p.py < f.screen_h;
 	return p;
 }
 

@@ -69,7 +69,7 @@ struct RowMap {
 	int32_t local_rows;    // rows held by the output buffer
 	int32_t band_rows;     // 0 = contiguous; else cyclic bands of this many rows
 	int32_t band_index, band_count;
-	int32_t tile_rot;      // launch order: workgroup i renders tile (i + tile_rot) mod n_tiles (api.cpp)
+	int32_t tile_rot;      // launch order: grid row j renders tile row (j + tile_rot) mod tile rows (api.cpp)
 };
 
 // Host: fill everything except the table pointers / thr_max / step_cap.

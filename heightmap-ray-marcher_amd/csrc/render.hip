@@ -80,11 +80,11 @@ __global__ __launch_bounds__(kBlockThreads) void k_render(const DevFrame f, cons
                                                 const double *__restrict__ thr,
                                                 const uint32_t *__restrict__ cmap,
                                                 uint32_t *__restrict__ out, int64_t out_stride_px,
-                                                int tiles_x, StatsOut st) {
+                                                int tiles_y, StatsOut st) {
 	// one small pixel tile per wave (device_common.hpp): neighbouring rays walk neighbouring
 	// ground tracks, so a wave's height loads share cache lines and its lanes leave the loop
 	// at similar times.
-	const PixelId pid = pixel_of_lane(f, rows, tiles_x);
+	const PixelId pid = pixel_of_lane(f, rows, tiles_y);
 	const int px = pid.px, py = pid.py, lrow = pid.lrow;
 	const bool live = pid.live;
 
@@ -218,19 +218,19 @@ static hipError_t launch_render_t(const DevFrame &f, const RowMap &rows, const d
 	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
 	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
 	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
-	const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y)), block(kBlockThreads);
+	const dim3 grid((unsigned)tiles_x, (unsigned)(tiles_y < 32768 ? tiles_y : 32768), (unsigned)((tiles_y + 32767) / 32768)), block(kBlockThreads);
 	switch (f.projection) {
 	case 1:
 		hipLaunchKernelGGL((k_render<1, STATS>), grid, block, 0, stream, f, rows, d_thr, d_cmap, d_out,
-		                   out_stride_px, tiles_x, st);
+		                   out_stride_px, tiles_y, st);
 		break;
 	case 2:
 		hipLaunchKernelGGL((k_render<2, STATS>), grid, block, 0, stream, f, rows, d_thr, d_cmap, d_out,
-		                   out_stride_px, tiles_x, st);
+		                   out_stride_px, tiles_y, st);
 		break;
 	default:
 		hipLaunchKernelGGL((k_render<3, STATS>), grid, block, 0, stream, f, rows, d_thr, d_cmap, d_out,
-		                   out_stride_px, tiles_x, st);
+		                   out_stride_px, tiles_y, st);
 		break;
 	}
 	return hipGetLastError();

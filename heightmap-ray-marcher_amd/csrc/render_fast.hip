@@ -189,8 +189,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
                                                      const double *__restrict__ thr,
                                                      const uint32_t *__restrict__ cmap,
                                                      uint32_t *__restrict__ out, int64_t out_stride_px,
-                                                     int tiles_x, StatsOut st) {
-	const PixelId pid = pixel_of_lane(f, rows, tiles_x);
+                                                     int tiles_y, StatsOut st) {
+	const PixelId pid = pixel_of_lane(f, rows, tiles_y);
 	const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull; // tools-only timing
 	unsigned long long my_steps = 0;
 	uint32_t my_hit = 0, my_cap = 0;
@@ -700,43 +700,43 @@ hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *
 // ---------------------------------------------------------------- launch ----
 template <int PROJ, bool STATS, int GWM, bool LEAP>
 static void launch_one(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
-                       uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid, int tiles_x,
+                       uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid, int tiles_y,
                        hipStream_t stream) {
 	if (f.sampling == 1)
 		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, true>), grid, dim3(kBlockThreads), 0, stream, f, rows,
-		                   d_thr, d_cmap, d_out, out_stride_px, tiles_x, st);
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
 	else
 		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, false>), grid, dim3(kBlockThreads), 0, stream, f, rows,
-		                   d_thr, d_cmap, d_out, out_stride_px, tiles_x, st);
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
 }
 
 template <int PROJ, bool STATS, int GWM>
 static void launch_leap(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
-                        int tiles_x, hipStream_t stream) {
-	if (leap) launch_one<PROJ, STATS, GWM, true>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream);
-	else launch_one<PROJ, STATS, GWM, false>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream);
+                        int tiles_y, hipStream_t stream) {
+	if (leap) launch_one<PROJ, STATS, GWM, true>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	else launch_one<PROJ, STATS, GWM, false>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 }
 
 template <int PROJ, bool STATS>
 static void launch_gwm(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                        const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
-                       int tiles_x, hipStream_t stream) {
+                       int tiles_y, hipStream_t stream) {
 	switch (f.grid_mode) {
-	case 0: launch_leap<PROJ, STATS, 0>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream); break;
-	case 1: launch_leap<PROJ, STATS, 1>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream); break;
-	default: launch_leap<PROJ, STATS, 2>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream); break;
+	case 0: launch_leap<PROJ, STATS, 0>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	case 1: launch_leap<PROJ, STATS, 1>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	default: launch_leap<PROJ, STATS, 2>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
 	}
 }
 
 template <bool STATS>
 static void launch_proj(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
-                        int tiles_x, hipStream_t stream) {
+                        int tiles_y, hipStream_t stream) {
 	switch (f.projection) {
-	case 1: launch_gwm<1, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream); break;
-	case 2: launch_gwm<2, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream); break;
-	default: launch_gwm<3, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream); break;
+	case 1: launch_gwm<1, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	case 2: launch_gwm<2, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	default: launch_gwm<3, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
 	}
 }
 
@@ -747,10 +747,10 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
 	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
 	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
-	const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y));
+	const dim3 grid((unsigned)tiles_x, (unsigned)(tiles_y < 32768 ? tiles_y : 32768), (unsigned)((tiles_y + 32767) / 32768));
 	StatsOut st{d_counters, d_steps, d_entry};
-	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream);
-	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_x, stream);
+	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 	return hipGetLastError();
 }
 

@@ -641,3 +641,20 @@ def test_launch_order_never_changes_a_pixel(gpu, oracle):
             fb, steps, plain, strip = frames[order]
             assert np.array_equal(fb, ofb) and np.array_equal(plain, ofb) and steps == total, (proj, order)
             assert np.array_equal(strip, ofb[48:131]), (proj, order)
+
+
+def test_very_tall_frame_uses_the_third_grid_dimension(gpu, oracle):
+    """More than 32768 tile rows (16 pixels each): the launch folds the rows into grid y and z."""
+    rgb, cmap = scenes.small_maps(40, 33, 77)
+    params = gpu.SceneParams.make(0.0, 6.0, grid_width=1.0)
+    cam = gpu.Camera.make(width=3, height=32768 * 16 + 37, projection=2, hfov=gpu.degrees_to_rads(20),
+                          hang=gpu.degrees_to_rads(-45), vang=gpu.degrees_to_rads(110), pos=(-6.0, 6.0, 9.0),
+                          step_dist=0.5, bg=(4, 5, 6))
+    heights = oracle.update_heightmap(rgb, params)
+    ofb, total, capped, *_ = oracle.render(oracle.make_cfg(cam, params, 40, 33), heights, cmap)
+    assert capped == 0
+    scene = gpu.Scene(rgb, cmap, params)
+    fb, st, *_ = scene.render_stats(cam)
+    assert st.rays == cam.width * cam.height and st.steps == total
+    assert np.array_equal(fb, ofb) and np.array_equal(scene.render(cam), ofb)
+    scene.close()
