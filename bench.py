@@ -10,21 +10,37 @@ render kernel over every pixel of the workload's framebuffer.  Default workload
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3]
   torchrun --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N = 1: K frames back to back, maps resident in HBM, output to a device buffer.
+N = 1: K frames of the workload's static pose back to back, maps resident in HBM,
+       output to a device buffer.
 N > 1: one process per GPU, maps replicated.  Default `--mode frames`: frames are
-       independent units (BASELINE config C5: frame k -> GPU k mod N), every rank
-       renders K whole frames, no data-path collective, scaling "weak".
+       independent units, sharded as BASELINE config C5 shards its recording: a
+       64-frame orbit of the workload's camera around the map centre, frame k on
+       GPU k mod N (rank r renders frames r, r+N, ... and wraps after 64), no
+       data-path collective, scaling "weak" (K frames per GPU whatever N).
        `--mode strips`: ONE frame is tiled into cyclic 16-row bands, strips gathered
-       on rank 0 over RCCL (config C4's pattern), scaling "strong" -- at ~0.3 ms per
+       on rank 0 over RCCL (config C4's pattern), scaling "strong" -- at ~0.1 ms per
        4K frame that mode measures the gather, not the kernel.
 
-Rank 0 prints ONE JSON line.  value = ray-steps/s, where a ray-step is one
-execution of the reference's height load (main/hmap.cpp:1013-1014); the count
-comes from the instrumented kernel variant (bit-identical pixels) run once,
-untimed.  roofline.achieved = algorithmic bytes (8 B/step + 4 B/ray + 4 B/hit,
-BASELINE.md) / mean kernel duration measured with HIP events on the launch
-stream.  cpu_baseline = the oracle (C port of the reference loop, OpenMP) timed
-on a bounded row sample of the same frame on this host.
+Rank 0 prints ONE JSON line.  value = REFERENCE-EQUIVALENT ray-steps/s: a ray-step is
+one execution of the reference's height load (main/hmap.cpp:1013-1014) and the count
+is what the reference executes for the same frame (instrumented kernel variant,
+bit-identical pixels, run once, untimed; equal to the oracle's count).  The
+production kernel proves most of those loads unnecessary and skips them, so the
+line also says `"equivalent_steps": true` and carries the height samples and
+pyramid look-ups the kernel really executes.
+
+roofline: the kernel is bound by VALU issue, not by HBM, so
+`bound` = "valu-issue": achieved = VALU pipe-busy SIMD-cycles per second (PMC counts
+from profiles/traffic.json priced with tools/valu_calib.hip's cycles per instruction
+class, over the kernel duration measured live with HIP events on the launch stream),
+peak = 1024 SIMDs x 2.4 GHz.  The PMC summary is only used when the hash of the
+kernel sources it was collected on equals this tree's (else frac is null).
+`hbm` holds measured HBM traffic / duration against the 8 TB/s peak; the
+BASELINE.md algorithmic-bytes figure (8 B per reference step) is kept under
+`algorithmic_equivalent` -- it exceeds the HBM peak because those loads are not
+executed, and is not a roofline fraction.
+cpu_baseline = the oracle (C port of the reference loop, OpenMP) timed on a bounded
+row sample of the same frame on this host.
 """
 import argparse
 import importlib
@@ -37,18 +53,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+SIMDS, PEAK_CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; max clock (MI355X_MICROARCH.md)
 BAND_ROWS = 16
+ORBIT_FRAMES = 64  # BASELINE config C5
 
 
-def _traffic_from_profiles(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary, if one exists
-    for this workload (profiles/traffic.json, written from a separate --pmc pass)."""
+def _pmc_from_profiles(workload, src_sha):
+    """The committed rocprofv3 PMC summary of this workload (profiles/traffic.json, written by
+    tools/pmc_summary.py from separate --pmc passes) -- only if it was collected on the kernel
+    sources of this tree.  Returns (entry or None, provenance dict)."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
+    prov = {"file": "profiles/traffic.json", "tree_kernel_src_sha": src_sha}
     try:
         with open(p) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            e = json.load(f).get(workload)
     except (OSError, ValueError):
-        return None
+        e = None
+    if not e:
+        prov["status"] = "no PMC summary for this workload"
+        return None, prov
+    prov.update(kernel_src_sha=e.get("kernel_src_sha"), git_commit=e.get("git_commit"), source=e.get("source"))
+    if e.get("kernel_src_sha") != src_sha:
+        prov["status"] = "stale: collected on other kernel sources; not used"
+        return None, prov
+    prov["status"] = "ok: collected on these kernel sources (separate rocprofv3 --pmc passes, not this run)"
+    return e, prov
 
 
 def cpu_baseline(hmrm, wl, rgb, cmap, params, cam, target_s=15.0):
@@ -145,15 +174,30 @@ def main():
     frame_steps, frame_rays, frame_hits = int(st.steps), int(st.rays), int(st.hits)
     algo_bytes = 8 * frame_steps + 4 * frame_rays + 4 * frame_hits
 
+    orbit = None
     if (world == 1 and not force_dist) or args.mode == "frames":
         out = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+        if world == 1:
+            def step():
+                scene.render_rows_device(cam, out.data_ptr(), W * 4, 0, H, stream=stream)
+            my_steps_timed = frame_steps * args.steps
+            parallelism = "1 GPU"
+        else:
+            # BASELINE config C5's sharding: frame k of the 64-frame orbit on GPU k mod world
+            mine = [k % ORBIT_FRAMES for k in range(rank, rank + world * (args.warmup + args.steps), world)]
+            cams = {k: wl.camera(k, ORBIT_FRAMES) for k in sorted(set(mine))}
+            steps_of = {k: int(scene.render_stats(c)[1].steps) for k, c in cams.items()}  # untimed, instrumented
+            orbit = {"it": iter(mine), "last": None}
 
-        def step():
-            scene.render_rows_device(cam, out.data_ptr(), W * 4, 0, H, stream=stream)
-        units_per_step = frame_steps * world  # every rank renders a whole frame
+            def step():
+                k = next(orbit["it"])
+                orbit["last"] = k
+                scene.render_rows_device(cams[k], out.data_ptr(), W * 4, 0, H, stream=stream)
+            my_steps_timed = sum(steps_of[k] for k in mine[args.warmup:])
+            parallelism = (f"{ORBIT_FRAMES}-frame orbit, frame k on GPU k mod {world} "
+                           f"({args.steps} frames per GPU), no collective")
         rays_per_step = frame_rays * world
         scaling = "weak"
-        parallelism = "1 GPU" if world == 1 else f"frame-parallel x{world}, no collective"
     else:
         plan = strips.BandPlan(height=H, width=W, band_rows=BAND_ROWS, world=world)
         strip = torch.zeros((plan.strip_rows, W, 4), dtype=torch.uint8, device="cuda")
@@ -166,7 +210,7 @@ def main():
 
         def step():
             result["frame"] = strips.render_frame_distributed(plan, rank, render_rows, dist, strip, block)
-        units_per_step = frame_steps
+        my_steps_timed = frame_steps * args.steps if rank == 0 else 0  # one frame per step for the whole job
         rays_per_step = frame_rays
         scaling = "strong"
         parallelism = f"cyclic {BAND_ROWS}-row bands over {world} GPUs + RCCL gather to rank 0"
@@ -184,13 +228,22 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    total_steps_timed = my_steps_timed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        n = torch.tensor([my_steps_timed], dtype=torch.int64, device="cuda")
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        total_steps_timed = int(n.item())
 
-    # correctness of what was just timed: the frame on rank 0 equals the single-GPU frame
-    if rank == 0:
+    # correctness of what was just timed: every rank's last frame equals what the instrumented
+    # kernel (another instantiation, host read-back path) renders for the same camera
+    if orbit is not None:
+        want = scene.render_stats(cams[orbit["last"]])[0]
+        if not np.array_equal(out.cpu().numpy(), want):
+            raise SystemExit(f"bench.py: rank {rank} rendered a different orbit frame {orbit['last']} than hmrm_render_stats")
+    elif rank == 0:
         got = (result["frame"] if ((world > 1 or force_dist) and args.mode == "strips") else out).cpu().numpy()
         if not np.array_equal(got, fb_ref):
             raise SystemExit("bench.py: timed path produced a different frame than hmrm_render_stats")
@@ -200,9 +253,34 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
-        value = units_per_step * args.steps / elapsed
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = _traffic_from_profiles(wl.name)
+        value = total_steps_timed / elapsed
+        kernel_s = kernel_ms * 1e-3
+        pmc, prov = _pmc_from_profiles(wl.name, hmrm.kernel_src_sha())
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        valu = (pmc or {}).get("valu") or {}
+        busy = valu.get("busy_cycles_weighted")
+        busy_upper = valu.get("busy_cycles_upper")
+        peak = SIMDS * PEAK_CLOCK_GHZ  # G SIMD-cycles/s
+        achieved = busy / kernel_s / 1e9 if busy else None
+        frac = achieved / peak if achieved else None
+        if frac is not None and frac > 1.0:  # a fraction above 1 would mean the pricing is wrong: do not print it
+            prov["status"] += "; weighted VALU figure exceeded the peak and was dropped"
+            achieved = frac = None
+        roofline = {
+            "bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s", "frac": frac,
+            "frac_if_every_valu_held_the_pipe_4_cycles": (busy_upper / kernel_s / 1e9 / peak) if busy_upper else None,
+            "traffic": traffic,
+            "hbm": {"achieved": (traffic / kernel_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None},
+            "lane_util": (pmc or {}).get("lane_util"),
+            "kernel": "k_render_fast (+ k_march_queue)", "kernel_ms": kernel_ms,
+            "kernel_ray_steps_per_s": frame_steps / kernel_s,
+            # BASELINE.md's nominal figure: bytes the REFERENCE's loop would move for this frame over the
+            # measured duration.  Not executed traffic (the loads are skipped), hence not a fraction of a peak.
+            "algorithmic_equivalent": {"bytes_per_launch": algo_bytes, "gbs": algo_bytes / kernel_s / 1e9,
+                                       "times_hbm_peak": algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS},
+            "pmc": prov,
+        }
         line = {
             "metric": "ray-steps/s at 3840x2160, 4096^2 heightmap" if wl.map_size == 4096 else
                       f"ray-steps/s at {W}x{H}, {wl.map_size}^2 heightmap",
@@ -210,6 +288,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "equivalent_steps": True,
+            "executed_per_frame": {"height_samples": int(st.groups) * 4 if st.groups else None,
+                                   "pyramid_lookups": int(st.leap_attempts),
+                                   "steps_covered_by_exact_leaps": int(st.leaped_steps)},
             "mrays_per_s": rays_per_step * args.steps / elapsed / 1e6,
             "config": {"workload": f"{wl.name}: {wl.map_size}x{wl.map_size} heightmap, {W}x{H}, "
                                    f"{('perspective', 'spherical', 'orthographic')[wl.projection - 1]} "
@@ -217,14 +299,7 @@ def main():
                        "ray_steps_per_frame": frame_steps, "rays_per_frame": frame_rays,
                        "hits_per_frame": frame_hits, "parallelism": parallelism,
                        "maps_sha256": hmrm.synth.maps_sha256(rgb, cmap)[:16]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_render_fast", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
-                         "kernel_ray_steps_per_s": frame_steps / (kernel_ms * 1e-3),
-                         # what the launch really moves (PMC, profiles/traffic.json) over the same duration:
-                         # the exact leaps skip most of the algorithmic loads, so frac > 1 is expected and
-                         # the kernel is VALU-issue / critical-path bound, not HBM bound
-                         "measured_hbm_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hmrm, wl, rgb, cmap, params, cam, args.cpu_seconds)

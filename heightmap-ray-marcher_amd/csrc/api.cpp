@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <new>
 #include <sstream>
 #include <string>
@@ -45,25 +46,84 @@ namespace {
 			return fail(HMRM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));    \
 	} while (0)
 
-int64_t default_step_cap() {
-	// The reference loop has no cap (hmap.cpp:1000).  2^26 steps is > 2800x the
-	// longest legitimate march of the largest BASELINE config (8192*sqrt(2)/0.5).
-	const char *s = getenv("HMRM_STEP_CAP");
-	if (s && *s) {
-		long long v = atoll(s);
-		if (v > 0) return (int64_t)v;
+// Environment knobs: read ONCE per scene at creation; the launch path never calls
+// getenv.  hmrm_debug_reload_env() re-reads them for a scene (tests and tools switch kernels on a
+// live scene).
+struct Knobs {
+	int64_t step_cap = (int64_t)1 << 26; // HMRM_STEP_CAP
+	int kernel = 0;                      // HMRM_KERNEL: 0 leap, 1 group, 2 simple
+	bool tile_order = true;              // HMRM_TILE_ORDER=0 -> row-major launch order
+	int diag_mode = 0;                   // HMRM_DIAG_ITERS (tools)
+	int min_level = -1;                  // HMRM_MIN_LEVEL (tools)
+	int pass1_trips = 24;                // HMRM_PASS1_TRIPS: loop trips before a ray is handed to the ray-queue kernel; 0 = single pass
+};
+
+Knobs read_knobs() {
+	Knobs k;
+	// The reference loop has no cap (hmap.cpp:1000).  2^26 steps is > 2800x the longest legitimate
+	// march of the largest BASELINE config (8192*sqrt(2)/0.5).  Both kernels count the budget in 32
+	// bits, so the cap is at most 2^31-1.
+	if (const char *s = getenv("HMRM_STEP_CAP")) {
+		const long long v = atoll(s);
+		if (v > 0) k.step_cap = v > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)v;
 	}
-	return (int64_t)1 << 26;
+	if (const char *s = getenv("HMRM_KERNEL")) k.kernel = strcmp(s, "simple") == 0 ? 2 : (strcmp(s, "group") == 0 ? 1 : 0);
+	if (const char *s = getenv("HMRM_TILE_ORDER")) k.tile_order = s[0] != '0';
+	if (const char *s = getenv("HMRM_DIAG_ITERS")) k.diag_mode = atoi(s);
+	if (const char *s = getenv("HMRM_MIN_LEVEL"))
+		if (s[0] >= '0' && s[0] < '0' + hmrm::kMipLevels) k.min_level = s[0] - '0';
+	if (const char *s = getenv("HMRM_PASS1_TRIPS")) {
+		const int v = atoi(s);
+		if (v >= 0) k.pass1_trips = v;
+	}
+	return k;
 }
 
 } // namespace
 
 constexpr int kCostRows = 8;
+constexpr int kFrameSlots = 4;   // cached per-frame records (and spherical tables) per stream
+constexpr int kMaxStreamCtx = 8; // streams a scene keeps launch state for
+
+// One cached per-frame record: the result of the host set-up (camera.cpp) for one camera, and for
+// spherical cameras its sin/cos tables on the device.  A pure function of (camera, scene params,
+// map size, thr_max), so a repeated camera re-renders without the libm calls or the upload.
+struct FrameSlot {
+	bool valid = false;
+	uint64_t stamp = 0; // last use (LRU)
+	hmrm_camera cam{};
+	hmrm_scene_params params{};
+	uint64_t thr_max_bits = 0;
+	hmrm::DevFrame frame{};
+	std::vector<float> row_cost; // per kCostRows screen rows: longest in-box ray, in steps (launch order hint)
+	double *d_tables = nullptr;  // spherical sin/cos tables
+	double *h_tables = nullptr;  // pinned staging
+	size_t tables_n = 0;
+	hipEvent_t uploaded = nullptr; // after the H2D copy out of h_tables: the host may rewrite them then
+};
+
+// Everything a launch mutates, per HIP stream: launches on different streams of one scene never
+// share a table, a queue or a counter (hmrm_render_rows_device takes the caller's stream).
+struct StreamCtx {
+	hipStream_t stream = nullptr;
+	uint64_t stamp = 0;
+	FrameSlot slots[kFrameSlots];
+	// ray queue of the two-pass march (frame.hpp RayQueue), grown on demand
+	double *q_pos = nullptr;  // x | y | z
+	int32_t *q_int = nullptr; // px | lrow | budget | lev
+	uint32_t q_capacity = 0;
+	uint32_t *q_count = nullptr; // two counters, used alternately: a frame's second pass zeroes the other one
+	int q_parity = 0;
+	// [0] steps [1] hits [2] capped rays (cumulative, never reset) [4..7] traversal diagnostics
+	unsigned long long *d_counters = nullptr;
+	unsigned long long capped_seen = 0; // value of [2] the host has already reported
+};
 
 struct hmrm_scene {
 	int device = 0;
 	int32_t map_w = 0, map_h = 0;
 	hmrm_scene_params params{};
+	Knobs knobs;
 	uint8_t *d_rgb = nullptr;   // W*H*3  base_heightmap_buf (hmap.cpp:51)
 	uint32_t *d_cmap = nullptr; // W*H    colormap_buf as packed RGBA (hmap.cpp:59)
 	double *d_thr = nullptr;    // W*H    heightmap_buf[i] + min_height
@@ -73,25 +133,20 @@ struct hmrm_scene {
 	float *d_mipbuf_bil = nullptr; // the same over the 3x3-dilated table (bilinear quality mode)
 	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/16/64/256-cell windows every 2/8/32/128 cells
 	int32_t mip_w[hmrm::kMipLevels] = {}, mip_h[hmrm::kMipLevels] = {}, mip_off[hmrm::kMipLevels] = {};
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr; // the scene's own stream (hmrm_render, updates)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	unsigned long long *d_counters = nullptr; // 8 x u64: steps, hits, capped, max key, 4 x traversal diagnostics
-	// per-render scratch, grown on demand (a scene is used by one host thread at a time)
+	unsigned long long *d_maxkey = nullptr; // UpdateHeightmap's max(thr) reduction
+	// scratch of the host-memory entry points (hmrm_render*, one caller at a time)
 	uint32_t *d_frame = nullptr;
 	size_t frame_px = 0;
-	double *d_tables = nullptr; // spherical sin/cos tables
-	double *h_tables = nullptr; // pinned staging
-	size_t tables_n = 0;
 	uint32_t *d_steps = nullptr;
 	double *d_entry = nullptr;
 	size_t stats_px = 0;
-	std::vector<float> row_cost; // per kCostRows screen rows: longest in-box ray, in steps (with the frame record)
-	// last per-frame record (see prepare_frame)
-	bool cache_valid = false;
-	hmrm_camera cache_cam{};
-	hmrm_scene_params cache_params{};
-	uint64_t cache_thr_max_bits = 0;
-	hmrm::DevFrame cache_frame{};
+	// launch state per stream; `mu` guards the list and the slot choice (launches themselves are
+	// asynchronous), so that threads driving different streams of one scene do not collide
+	std::mutex mu;
+	std::vector<StreamCtx *> ctxs;
+	uint64_t clock = 0;
 };
 
 struct hmrm_config {
@@ -101,6 +156,72 @@ struct hmrm_config {
 
 namespace {
 
+void destroy_ctx(StreamCtx *c) {
+	if (!c) return;
+	for (FrameSlot &sl : c->slots) {
+		if (sl.d_tables) (void)hipFree(sl.d_tables);
+		if (sl.h_tables) (void)hipHostFree(sl.h_tables);
+		if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+	}
+	if (c->q_pos) (void)hipFree(c->q_pos);
+	if (c->q_int) (void)hipFree(c->q_int);
+	if (c->q_count) (void)hipFree(c->q_count);
+	if (c->d_counters) (void)hipFree(c->d_counters);
+	delete c;
+}
+
+// The launch state of `stream` (created on first use; the least recently used one is dropped, after
+// its stream has drained, when a scene is driven from more than kMaxStreamCtx streams).
+int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
+	for (StreamCtx *c : s->ctxs)
+		if (c->stream == stream) {
+			c->stamp = ++s->clock;
+			*out = c;
+			return HMRM_OK;
+		}
+	if ((int)s->ctxs.size() >= kMaxStreamCtx) {
+		size_t victim = 1; // (never the scene's own stream, entry 0)
+		for (size_t i = 2; i < s->ctxs.size(); ++i)
+			if (s->ctxs[i]->stamp < s->ctxs[victim]->stamp) victim = i;
+		(void)hipStreamSynchronize(s->ctxs[victim]->stream);
+		destroy_ctx(s->ctxs[victim]);
+		s->ctxs.erase(s->ctxs.begin() + (long)victim);
+	}
+	StreamCtx *c = new (std::nothrow) StreamCtx();
+	if (!c) return fail(HMRM_E_ARG, "out of memory");
+	c->stream = stream;
+	c->stamp = ++s->clock;
+	hipError_t e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void **)&c->q_count, 2 * sizeof(uint32_t));
+	// (zeroed on the scene's stream and waited for: the caller's stream may be anything)
+	if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(c->q_count, 0, 2 * sizeof(uint32_t), s->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+	if (e != hipSuccess) {
+		destroy_ctx(c);
+		return fail(HMRM_E_DEVICE, std::string("stream context: ") + hipGetErrorString(e));
+	}
+	s->ctxs.push_back(c);
+	*out = c;
+	return HMRM_OK;
+}
+
+// Ray queue of at least `want` entries (frame.hpp RayQueue).  Growing it happens between frames of
+// this stream only, after the stream has drained.
+int ensure_queue(StreamCtx *c, uint32_t want) {
+	if (want <= c->q_capacity) return HMRM_OK;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (c->q_pos) (void)hipFree(c->q_pos);
+	if (c->q_int) (void)hipFree(c->q_int);
+	c->q_pos = nullptr;
+	c->q_int = nullptr;
+	c->q_capacity = 0;
+	HIP_TRY(hipMalloc((void **)&c->q_pos, (size_t)want * 3 * sizeof(double)));
+	HIP_TRY(hipMalloc((void **)&c->q_int, (size_t)want * 4 * sizeof(int32_t)));
+	c->q_capacity = want;
+	return HMRM_OK;
+}
+
 // Launch order.  Workgroups start in index order, and the waves that graze the terrain near the
 // horizon run 50-100x longer than the rest: if their tile rows come late in the grid, the whole
 // launch waits for them with most of the chip idle (C3: up to +45 %).  So the grid is rotated to
@@ -108,9 +229,8 @@ namespace {
 // a tenth of the frame's maximum: the long rows start first, the cost then falls off towards
 // the bottom of the frame, and the rows above (sky, or short marches) fill the tail.
 // Scheduling only; HMRM_TILE_ORDER=0 keeps row-major order for A/B runs.
-int choose_tile_rot(const hmrm_scene *s, const hmrm::DevFrame &f, const hmrm::RowMap &rows) {
-	const char *ord = getenv("HMRM_TILE_ORDER");
-	if ((ord && ord[0] == '0') || rows.band_rows > 0 || s->row_cost.empty()) return 0;
+int choose_tile_rot(const hmrm_scene *s, const std::vector<float> &row_cost, const hmrm::RowMap &rows) {
+	if (!s->knobs.tile_order || rows.band_rows > 0 || row_cost.empty()) return 0;
 	int tile_w = 1, tile_h = 1;
 	hmrm::render_tile_shape(&tile_w, &tile_h);
 	const int tiles_y = (rows.local_rows + tile_h - 1) / tile_h;
@@ -118,8 +238,8 @@ int choose_tile_rot(const hmrm_scene *s, const hmrm::DevFrame &f, const hmrm::Ro
 	auto tile_cost = [&](int t) {
 		float c = 0.0f;
 		const int r0 = rows.row_begin + t * tile_h, r1 = r0 + tile_h - 1;
-		for (int k = r0 / kCostRows; k <= r1 / kCostRows && k < (int)s->row_cost.size(); ++k)
-			if (s->row_cost[(size_t)k] > c) c = s->row_cost[(size_t)k];
+		for (int k = r0 / kCostRows; k <= r1 / kCostRows && k < (int)row_cost.size(); ++k)
+			if (row_cost[(size_t)k] > c) c = row_cost[(size_t)k];
 		return c;
 	};
 	float top = 0.0f;
@@ -128,59 +248,6 @@ int choose_tile_rot(const hmrm_scene *s, const hmrm::DevFrame &f, const hmrm::Ro
 	for (int t = 0; t < tiles_y; ++t)
 		if (tile_cost(t) >= 0.1f * top) return t;
 	return 0;
-}
-
-// Kernel variant: "leap" (default; speculative groups + exact leaps), "group"
-// (speculative groups only), "simple" (the literal one-step-at-a-time loop, kept for A/B
-// runs and as an in-library cross-check).  All three produce identical pixels and counts.
-hipError_t launch_variant(const hmrm::DevFrame &f, const hmrm::RowMap &rows, const hmrm_scene *s,
-                          uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry,
-                          bool stats, hipStream_t stream) {
-	hmrm::RowMap rows_in_order = rows;
-	rows_in_order.tile_rot = choose_tile_rot(s, f, rows);
-	const char *k = getenv("HMRM_KERNEL");
-	if (k && strcmp(k, "simple") == 0 && f.sampling == 0) // (the literal loop only knows the reference's sampling)
-		return hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, s->d_counters, d_steps,
-		                           d_entry, stats, stream);
-	const bool leap = !(k && strcmp(k, "group") == 0);
-	return hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, s->d_counters,
-	                                d_steps, d_entry, stats, leap, stream);
-}
-
-int ensure_frame(hmrm_scene *s, size_t px) {
-	if (px <= s->frame_px) return HMRM_OK;
-	if (s->d_frame) (void)hipFree(s->d_frame);
-	s->d_frame = nullptr;
-	s->frame_px = 0;
-	HIP_TRY(hipMalloc((void **)&s->d_frame, px * sizeof(uint32_t)));
-	s->frame_px = px;
-	return HMRM_OK;
-}
-
-int ensure_tables(hmrm_scene *s, size_t n) {
-	if (n <= s->tables_n) return HMRM_OK;
-	if (s->d_tables) (void)hipFree(s->d_tables);
-	if (s->h_tables) (void)hipHostFree(s->h_tables);
-	s->d_tables = nullptr;
-	s->h_tables = nullptr;
-	s->tables_n = 0;
-	HIP_TRY(hipMalloc((void **)&s->d_tables, n * sizeof(double)));
-	HIP_TRY(hipHostMalloc((void **)&s->h_tables, n * sizeof(double), hipHostMallocDefault));
-	s->tables_n = n;
-	return HMRM_OK;
-}
-
-int ensure_stats(hmrm_scene *s, size_t px) {
-	if (px <= s->stats_px) return HMRM_OK;
-	if (s->d_steps) (void)hipFree(s->d_steps);
-	if (s->d_entry) (void)hipFree(s->d_entry);
-	s->d_steps = nullptr;
-	s->d_entry = nullptr;
-	s->stats_px = 0;
-	HIP_TRY(hipMalloc((void **)&s->d_steps, px * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void **)&s->d_entry, px * sizeof(double)));
-	s->stats_px = px;
-	return HMRM_OK;
 }
 
 int check_camera(const hmrm_camera *cam) {
@@ -194,94 +261,177 @@ int check_camera(const hmrm_camera *cam) {
 
 int ensure_bilinear_pyramid(hmrm_scene *s);
 
-// Host set-up for one frame: fills `f` and, for spherical, enqueues the table upload.
-// The result is a pure function of (camera, scene params, map size), so the last one is
-// kept: a static camera re-renders without redoing the libm calls or the table upload
-// (the reference rebuilds its ImagePlane every frame, hmap.cpp:952-965; same values).
-int prepare_frame_uncached(hmrm_scene *s, const hmrm_camera *cam, hipStream_t stream, hmrm::DevFrame *f);
+void to_host_camera(const hmrm_camera *cam, hmrm::HostCamera *hc) {
+	*hc = hmrm::HostCamera{};
+	hc->width = cam->width;
+	hc->height = cam->height;
+	hc->projection = cam->projection;
+	hc->bg_r = cam->bg_r;
+	hc->bg_g = cam->bg_g;
+	hc->bg_b = cam->bg_b;
+	hc->sampling = cam->sampling;
+	hc->hfov = cam->hfov;
+	hc->hang = cam->hang;
+	hc->vang = cam->vang;
+	hc->pos[0] = cam->pos[0];
+	hc->pos[1] = cam->pos[1];
+	hc->pos[2] = cam->pos[2];
+	hc->ortho_width = cam->ortho_width;
+	hc->step_dist = cam->step_dist;
+}
 
-int prepare_frame(hmrm_scene *s, const hmrm_camera *cam, hipStream_t stream, hmrm::DevFrame *f) {
-	const bool same = s->cache_valid && memcmp(&s->cache_cam, cam, sizeof *cam) == 0 &&
-	                  memcmp(&s->cache_params, &s->params, sizeof s->params) == 0 &&
-	                  s->cache_thr_max_bits == *(const uint64_t *)&s->thr_max;
-	if (!same) {
-		s->cache_valid = false;
-		int rc = prepare_frame_uncached(s, cam, stream, &s->cache_frame);
-		if (rc) return rc;
+// Host set-up for one frame (the reference rebuilds its ImagePlane every frame, hmap.cpp:952-965;
+// same values): finds the stream's cached record for this camera or builds it into the least
+// recently used slot; for spherical cameras the table upload is enqueued on the launch stream, in
+// front of the kernel that reads it.  *slot_out stays valid until the next call on this context.
+int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::DevFrame *f, FrameSlot **slot_out) {
+	const uint64_t thr_bits = *(const uint64_t *)&s->thr_max;
+	FrameSlot *slot = nullptr;
+	for (FrameSlot &sl : c->slots)
+		if (sl.valid && memcmp(&sl.cam, cam, sizeof *cam) == 0 && memcmp(&sl.params, &s->params, sizeof s->params) == 0 &&
+		    sl.thr_max_bits == thr_bits)
+			slot = &sl;
+	if (!slot) {
+		slot = &c->slots[0];
+		for (FrameSlot &sl : c->slots)
+			if (!sl.valid || sl.stamp < slot->stamp) {
+				slot = &sl;
+				if (!sl.valid) break;
+			}
+		slot->valid = false;
+		hmrm::HostCamera hc;
+		to_host_camera(cam, &hc);
+		double *cc = nullptr, *cs = nullptr, *rs = nullptr, *rc = nullptr;
+		const size_t W = (size_t)cam->width, H = (size_t)cam->height;
 		if (cam->projection == HMRM_SPHERICAL) {
-			// the tables must be on the device before a later launch on ANOTHER stream reads them
-			HIP_TRY(hipStreamSynchronize(stream));
+			const size_t n = 2 * W + 2 * H;
+			if (n > slot->tables_n) {
+				// (a kernel of this stream may still read the old tables)
+				HIP_TRY(hipStreamSynchronize(c->stream));
+				if (slot->d_tables) (void)hipFree(slot->d_tables);
+				if (slot->h_tables) (void)hipHostFree(slot->h_tables);
+				slot->d_tables = nullptr;
+				slot->h_tables = nullptr;
+				slot->tables_n = 0;
+				HIP_TRY(hipMalloc((void **)&slot->d_tables, n * sizeof(double)));
+				HIP_TRY(hipHostMalloc((void **)&slot->h_tables, n * sizeof(double), hipHostMallocDefault));
+				slot->tables_n = n;
+			}
+			if (!slot->uploaded) HIP_TRY(hipEventCreateWithFlags(&slot->uploaded, hipEventDisableTiming));
+			else HIP_TRY(hipEventSynchronize(slot->uploaded)); // the previous upload out of h_tables is done
+			cc = slot->h_tables;
+			cs = cc + W;
+			rs = cs + W;
+			rc = rs + H;
 		}
-		s->cache_cam = *cam;
-		s->cache_params = s->params;
-		s->cache_thr_max_bits = *(const uint64_t *)&s->thr_max;
-		s->cache_valid = true;
+		hmrm::DevFrame &fr = slot->frame;
+		hmrm::build_frame(hc, s->map_w, s->map_h, s->params.min_height, s->params.max_height, s->params.grid_width,
+		                  &fr, cc, cs, rs, rc);
+		slot->row_cost.assign(((size_t)cam->height + kCostRows - 1) / kCostRows, 0.0f);
+		hmrm::estimate_row_costs(fr, cc, cs, rs, rc, kCostRows, slot->row_cost.data());
+		if (cam->projection == HMRM_SPHERICAL) {
+			// stream order puts the copy behind every earlier kernel of this stream that read the
+			// slot's device tables and in front of the kernel about to be launched
+			HIP_TRY(hipMemcpyAsync(slot->d_tables, slot->h_tables, (2 * W + 2 * H) * sizeof(double),
+			                       hipMemcpyHostToDevice, c->stream));
+			HIP_TRY(hipEventRecord(slot->uploaded, c->stream));
+			fr.col_cos_ha = slot->d_tables;
+			fr.col_sin_ha = slot->d_tables + W;
+			fr.row_sin_va = slot->d_tables + 2 * W;
+			fr.row_cos_va = slot->d_tables + 2 * W + H;
+		}
+		if (cam->sampling == HMRM_BILINEAR) {
+			const int rc2 = ensure_bilinear_pyramid(s);
+			if (rc2 != HMRM_OK) return rc2;
+		}
+		fr.thr_max = cam->sampling == HMRM_BILINEAR ? s->thr_max_bil : s->thr_max;
+		// the finest level whose windows have at least min_window cells (camera.cpp's hint)
+		fr.min_level = 0;
+		while (fr.min_level < hmrm::kMipLevels - 1 && (2 << hmrm::mip_stride_shift(fr.min_level)) < fr.min_window)
+			++fr.min_level;
+		fr.mipbuf = s->d_mipbuf;
+		fr.mipbuf_bil = s->d_mipbuf_bil;
+		for (int l = 0; l < hmrm::kMipLevels; ++l) fr.mip_off[l] = s->mip_off[l];
+		slot->cam = *cam;
+		slot->params = s->params;
+		slot->thr_max_bits = thr_bits;
+		slot->valid = true;
 	}
-	*f = s->cache_frame;
-	// per-call settings from the environment (not part of the cached record)
-	f->step_cap = default_step_cap();
-	// tools only: HMRM_DIAG_ITERS=n makes the instrumented kernel report diagnostics instead of step
-	// counts (render_fast.hip), HMRM_MIN_LEVEL=l overrides the finest pyramid level attempted
-	const char *dg = getenv("HMRM_DIAG_ITERS");
-	f->diag_mode = dg ? atoi(dg) : 0;
-	const char *ml = getenv("HMRM_MIN_LEVEL");
-	if (ml && ml[0] >= '0' && ml[0] < '0' + hmrm::kMipLevels) f->min_level = ml[0] - '0';
+	slot->stamp = ++s->clock;
+	*f = slot->frame;
+	// per-scene settings (not part of the cached record)
+	f->step_cap = s->knobs.step_cap;
+	f->diag_mode = s->knobs.diag_mode;
+	if (s->knobs.min_level >= 0) f->min_level = s->knobs.min_level;
+	if (slot_out) *slot_out = slot;
 	return HMRM_OK;
 }
 
-int prepare_frame_uncached(hmrm_scene *s, const hmrm_camera *cam, hipStream_t stream, hmrm::DevFrame *f) {
-	hmrm::HostCamera hc{};
-	hc.width = cam->width;
-	hc.height = cam->height;
-	hc.projection = cam->projection;
-	hc.bg_r = cam->bg_r;
-	hc.bg_g = cam->bg_g;
-	hc.bg_b = cam->bg_b;
-	hc.sampling = cam->sampling;
-	hc.hfov = cam->hfov;
-	hc.hang = cam->hang;
-	hc.vang = cam->vang;
-	hc.pos[0] = cam->pos[0];
-	hc.pos[1] = cam->pos[1];
-	hc.pos[2] = cam->pos[2];
-	hc.ortho_width = cam->ortho_width;
-	hc.step_dist = cam->step_dist;
-	double *cc = nullptr, *cs = nullptr, *rs = nullptr, *rc = nullptr;
-	const size_t W = (size_t)cam->width, H = (size_t)cam->height;
-	if (cam->projection == HMRM_SPHERICAL) {
-		int rc_ = ensure_tables(s, 2 * W + 2 * H);
-		if (rc_) return rc_;
-		cc = s->h_tables;
-		cs = cc + W;
-		rs = cs + W;
-		rc = rs + H;
+// One frame (or row strip) on the context's stream.  Kernel variant: "leap" (default; speculative
+// groups + exact leaps, two passes), "group" (speculative groups only), "simple" (the literal
+// one-step-at-a-time loop, kept for A/B runs and as an in-library cross-check).  All produce
+// identical pixels and counts.
+int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const FrameSlot *slot, const hmrm::RowMap &rows,
+                 uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats) {
+	hmrm::RowMap rows_in_order = rows;
+	rows_in_order.tile_rot = choose_tile_rot(s, slot->row_cost, rows);
+	if (s->knobs.kernel == 2 && f.sampling == 0) { // (the literal loop only knows the reference's sampling)
+		HIP_TRY(hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters, d_steps,
+		                            d_entry, stats, c->stream));
+		return HMRM_OK;
 	}
-	hmrm::build_frame(hc, s->map_w, s->map_h, s->params.min_height, s->params.max_height,
-	                  s->params.grid_width, f, cc, cs, rs, rc);
-	// launch-order hint for this frame (choose_tile_rot)
-	s->row_cost.assign(((size_t)cam->height + kCostRows - 1) / kCostRows, 0.0f);
-	hmrm::estimate_row_costs(*f, cc, cs, rs, rc, kCostRows, s->row_cost.data());
-	if (cam->projection == HMRM_SPHERICAL) {
-		HIP_TRY(hipMemcpyAsync(s->d_tables, s->h_tables, (2 * W + 2 * H) * sizeof(double),
-		                       hipMemcpyHostToDevice, stream));
-		f->col_cos_ha = s->d_tables;
-		f->col_sin_ha = s->d_tables + W;
-		f->row_sin_va = s->d_tables + 2 * W;
-		f->row_cos_va = s->d_tables + 2 * W + H;
+	const bool leap = s->knobs.kernel != 1;
+	hmrm::RayQueue q{};
+	const bool two_pass = leap && f.sampling == 0 && s->knobs.pass1_trips > 0 && f.diag_mode == 0;
+	if (two_pass) {
+		// room for a quarter of the launch's rays (at least 64 Ki): more than ever queue up in
+		// practice, and a full queue only means the surplus finishes in the first pass
+		const int64_t px = (int64_t)f.screen_w * rows.local_rows;
+		const uint32_t want = (uint32_t)std::min<int64_t>(std::max<int64_t>(px / 4, 1 << 16), (int64_t)1 << 26);
+		const int rc = ensure_queue(c, want);
+		if (rc) return rc;
+		const size_t n = c->q_capacity;
+		q.x = c->q_pos;
+		q.y = c->q_pos + n;
+		q.z = c->q_pos + 2 * n;
+		q.px = c->q_int;
+		q.lrow = c->q_int + n;
+		q.budget = c->q_int + 2 * n;
+		q.lev = c->q_int + 3 * n;
+		q.count = c->q_count + c->q_parity;
+		q.capacity = c->q_capacity;
+		q.pass1_trips = s->knobs.pass1_trips;
 	}
-	if (cam->sampling == HMRM_BILINEAR) {
-		const int rc = ensure_bilinear_pyramid(s);
-		if (rc != HMRM_OK) return rc;
+	HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters,
+	                                 d_steps, d_entry, stats, leap, q, c->stream));
+	if (two_pass) {
+		HIP_TRY(hmrm::launch_march_queue(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters,
+		                                 d_steps, stats, q, c->q_count + (c->q_parity ^ 1), c->stream));
+		c->q_parity ^= 1;
 	}
-	f->thr_max = cam->sampling == HMRM_BILINEAR ? s->thr_max_bil : s->thr_max;
-	f->step_cap = default_step_cap();
-	// the finest level whose windows have at least min_window cells (camera.cpp's hint)
-	f->min_level = 0;
-	while (f->min_level < hmrm::kMipLevels - 1 && (2 << hmrm::mip_stride_shift(f->min_level)) < f->min_window)
-		++f->min_level;
-	f->mipbuf = s->d_mipbuf;
-	f->mipbuf_bil = s->d_mipbuf_bil;
-	for (int l = 0; l < hmrm::kMipLevels; ++l) f->mip_off[l] = s->mip_off[l];
+	return HMRM_OK;
+}
+
+int ensure_frame(hmrm_scene *s, size_t px) {
+	if (px <= s->frame_px) return HMRM_OK;
+	if (s->d_frame) (void)hipFree(s->d_frame);
+	s->d_frame = nullptr;
+	s->frame_px = 0;
+	HIP_TRY(hipMalloc((void **)&s->d_frame, px * sizeof(uint32_t)));
+	s->frame_px = px;
+	return HMRM_OK;
+}
+
+int ensure_stats(hmrm_scene *s, size_t px) {
+	if (px <= s->stats_px) return HMRM_OK;
+	if (s->d_steps) (void)hipFree(s->d_steps);
+	if (s->d_entry) (void)hipFree(s->d_entry);
+	s->d_steps = nullptr;
+	s->d_entry = nullptr;
+	s->stats_px = 0;
+	HIP_TRY(hipMalloc((void **)&s->d_steps, px * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc((void **)&s->d_entry, px * sizeof(double)));
+	s->stats_px = px;
 	return HMRM_OK;
 }
 
@@ -316,12 +466,15 @@ int ensure_bilinear_pyramid(hmrm_scene *s) {
 	return HMRM_OK;
 }
 
+// UpdateHeightmap + pyramid on the scene's stream.  Streams other than the scene's own must not
+// have launches in flight while the heights change (as in the reference, where UpdateHeightmap runs
+// between frames, hmap.cpp:517-519).
 int run_update_heights(hmrm_scene *s) {
 	const int64_t n = (int64_t)s->map_w * s->map_h;
-	HIP_TRY(hipMemsetAsync(s->d_counters + 3, 0, sizeof(unsigned long long), s->stream));
+	HIP_TRY(hipMemsetAsync(s->d_maxkey, 0, sizeof(unsigned long long), s->stream));
 	HIP_TRY(hmrm::launch_prepare_heights(s->d_rgb, s->d_thr, n, s->params.lum_r, s->params.lum_g,
 	                                     s->params.lum_b, s->params.min_height, s->params.max_height,
-	                                     false, s->d_counters + 3, s->stream));
+	                                     false, s->d_maxkey, s->stream));
 	// window-maximum pyramid for the exact-leap traversal (render_fast.hip)
 	HIP_TRY(hmrm::launch_build_mip0(s->d_thr, s->map_w, s->map_h, s->d_mipbuf + s->mip_off[0], s->mip_w[0],
 	                                s->mip_h[0], s->stream));
@@ -329,12 +482,29 @@ int run_update_heights(hmrm_scene *s) {
 		HIP_TRY(hmrm::launch_build_mip_up(s->d_mipbuf + s->mip_off[l - 1], s->mip_w[l - 1], s->mip_h[l - 1],
 		                                  s->d_mipbuf + s->mip_off[l], s->mip_w[l], s->mip_h[l], s->stream));
 	s->bil_valid = false; // rebuilt by the next bilinear frame
-	s->cache_valid = false;
+	for (StreamCtx *c : s->ctxs)
+		for (FrameSlot &sl : c->slots) sl.valid = false;
 	unsigned long long key = 0;
-	HIP_TRY(hipMemcpyAsync(&key, s->d_counters + 3, sizeof key, hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipMemcpyAsync(&key, s->d_maxkey, sizeof key, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->thr_max = key ? hmrm::max_key_to_double(key) : -__builtin_huge_val();
 	return HMRM_OK;
+}
+
+// Rays of this context that reached the step cap since the host last asked (the stream must be idle).
+int take_capped(StreamCtx *c, unsigned long long *out) {
+	unsigned long long now = 0;
+	HIP_TRY(hipMemcpy(&now, c->d_counters + 2, sizeof now, hipMemcpyDeviceToHost));
+	*out = now - c->capped_seen;
+	c->capped_seen = now;
+	return HMRM_OK;
+}
+
+int noterm(unsigned long long capped) {
+	char buf[160];
+	snprintf(buf, sizeof buf, "%llu ray(s) reached the step cap; the reference's loop would not terminate for them",
+	         capped);
+	return fail(HMRM_E_NOTERM, buf);
 }
 
 } // namespace
@@ -370,6 +540,7 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 	s->map_w = map_w;
 	s->map_h = map_h;
 	s->params = *params;
+	s->knobs = read_knobs();
 	int rc = HMRM_OK;
 	auto body = [&]() -> int {
 		HIP_TRY(hipGetDevice(&s->device));
@@ -391,10 +562,12 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 			HIP_TRY(hipMalloc((void **)&s->d_mipbuf, total * sizeof(float)));
 			HIP_TRY(hipMalloc((void **)&s->d_mipbuf_bil, total * sizeof(float)));
 		}
-		HIP_TRY(hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long)));
-		HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), s->stream));
+		HIP_TRY(hipMalloc((void **)&s->d_maxkey, sizeof(unsigned long long)));
 		HIP_TRY(hipMemcpyAsync(s->d_rgb, height_rgb, n * 3, hipMemcpyHostToDevice, s->stream));
 		HIP_TRY(hipMemcpyAsync(s->d_cmap, color_rgba, n * 4, hipMemcpyHostToDevice, s->stream));
+		StreamCtx *own = nullptr;
+		const int rc2 = ctx_for(s, s->stream, &own); // entry 0: the scene's own stream
+		if (rc2) return rc2;
 		return run_update_heights(s);
 	};
 	rc = body();
@@ -411,6 +584,7 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 int hmrm_scene_update(hmrm_scene *s, const hmrm_scene_params *params) {
 	if (!s || !params) return fail(HMRM_E_ARG, "NULL argument");
 	HIP_TRY(hipSetDevice(s->device));
+	std::lock_guard<std::mutex> lk(s->mu);
 	s->params = *params;
 	return run_update_heights(s);
 }
@@ -418,22 +592,32 @@ int hmrm_scene_update(hmrm_scene *s, const hmrm_scene_params *params) {
 void hmrm_scene_destroy(hmrm_scene *s) {
 	if (!s) return;
 	(void)hipSetDevice(s->device);
-	if (s->stream) (void)hipStreamSynchronize(s->stream);
+	for (StreamCtx *c : s->ctxs) {
+		// (a caller's stream may already be gone: only the scene's own stream is drained)
+		if (c->stream == s->stream && s->stream) (void)hipStreamSynchronize(s->stream);
+		destroy_ctx(c);
+	}
+	s->ctxs.clear();
 	if (s->d_rgb) (void)hipFree(s->d_rgb);
 	if (s->d_cmap) (void)hipFree(s->d_cmap);
 	if (s->d_thr) (void)hipFree(s->d_thr);
 	if (s->d_mipbuf) (void)hipFree(s->d_mipbuf);
 	if (s->d_mipbuf_bil) (void)hipFree(s->d_mipbuf_bil);
-	if (s->d_counters) (void)hipFree(s->d_counters);
+	if (s->d_maxkey) (void)hipFree(s->d_maxkey);
 	if (s->d_frame) (void)hipFree(s->d_frame);
-	if (s->d_tables) (void)hipFree(s->d_tables);
-	if (s->h_tables) (void)hipHostFree(s->h_tables);
 	if (s->d_steps) (void)hipFree(s->d_steps);
 	if (s->d_entry) (void)hipFree(s->d_entry);
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
 	if (s->ev1) (void)hipEventDestroy(s->ev1);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	delete s;
+}
+
+int hmrm_debug_reload_env(hmrm_scene *s) {
+	if (!s) return fail(HMRM_E_ARG, "NULL argument");
+	std::lock_guard<std::mutex> lk(s->mu);
+	s->knobs = read_knobs();
+	return HMRM_OK;
 }
 
 int hmrm_scene_read_heights(const hmrm_scene *cs, double *out) {
@@ -462,21 +646,28 @@ static int render_common(hmrm_scene *s, const hmrm_camera *cam, uint8_t *rgba, s
 	const size_t W = (size_t)cam->width, H = (size_t)cam->height;
 	if (stride_bytes < W * 4) return fail(HMRM_E_ARG, "stride_bytes < width*4");
 	HIP_TRY(hipSetDevice(s->device));
+	std::lock_guard<std::mutex> lk(s->mu);
 	if ((rc = ensure_frame(s, W * H))) return rc;
 	if (want_stats && (rc = ensure_stats(s, W * H))) return rc;
+	StreamCtx *c = nullptr;
+	if ((rc = ctx_for(s, s->stream, &c))) return rc;
 	hmrm::DevFrame f;
-	if ((rc = prepare_frame(s, cam, s->stream, &f))) return rc;
+	FrameSlot *slot = nullptr;
+	if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
 	hmrm::RowMap rows{0, cam->height, 0, 0, 1, 0};
-	HIP_TRY(hipMemsetAsync(s->d_counters, 0, 3 * sizeof(unsigned long long), s->stream));
-	HIP_TRY(hipMemsetAsync(s->d_counters + 4, 0, 4 * sizeof(unsigned long long), s->stream));
+	if (want_stats) {
+		HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), s->stream));
+		HIP_TRY(hipMemsetAsync(c->d_counters + 4, 0, 4 * sizeof(unsigned long long), s->stream));
+	}
 	HIP_TRY(hipEventRecord(s->ev0, s->stream));
-	HIP_TRY(launch_variant(f, rows, s, s->d_frame, (int64_t)W, want_stats ? s->d_steps : nullptr,
-	                       want_stats ? s->d_entry : nullptr, want_stats, s->stream));
+	if ((rc = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, want_stats ? s->d_steps : nullptr,
+	                       want_stats ? s->d_entry : nullptr, want_stats)))
+		return rc;
 	HIP_TRY(hipEventRecord(s->ev1, s->stream));
 	HIP_TRY(hipMemcpy2DAsync(rgba, stride_bytes, s->d_frame, W * 4, W * 4, H, hipMemcpyDeviceToHost,
 	                         s->stream));
 	unsigned long long counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	HIP_TRY(hipMemcpyAsync(counters, s->d_counters, sizeof counters, hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipMemcpyAsync(counters, c->d_counters, sizeof counters, hipMemcpyDeviceToHost, s->stream));
 	if (want_stats && steps_pp)
 		HIP_TRY(hipMemcpyAsync(steps_pp, s->d_steps, W * H * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
 	if (want_stats && entry_d)
@@ -485,23 +676,19 @@ static int render_common(hmrm_scene *s, const hmrm_camera *cam, uint8_t *rgba, s
 	float ms = 0.f;
 	HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
 	g_last_kernel_ms = ms;
+	const unsigned long long capped = counters[2] - c->capped_seen;
+	c->capped_seen = counters[2];
 	if (stats) {
 		stats->rays = (uint64_t)W * H;
 		stats->steps = counters[0];
 		stats->hits = counters[1];
-		stats->capped = counters[2];
+		stats->capped = capped;
 		stats->leap_attempts = counters[4];
 		stats->leaps = counters[5];
 		stats->groups = counters[6];
 		stats->leaped_steps = counters[7];
 	}
-	if (counters[2]) {
-		char buf[160];
-		snprintf(buf, sizeof buf,
-		         "%llu ray(s) reached the step cap; the reference's loop would not terminate for them",
-		         counters[2]);
-		return fail(HMRM_E_NOTERM, buf);
-	}
+	if (capped) return noterm(capped);
 	return HMRM_OK;
 }
 
@@ -569,12 +756,31 @@ int hmrm_render_rows_device(const hmrm_scene *scene, const hmrm_camera *cam, voi
 		rows.band_count = 1;
 	}
 	HIP_TRY(hipSetDevice(s->device));
-	hipStream_t stream = (hipStream_t)hip_stream;
+	std::lock_guard<std::mutex> lk(s->mu);
+	StreamCtx *c = nullptr;
+	if ((rc = ctx_for(s, (hipStream_t)hip_stream, &c))) return rc;
 	hmrm::DevFrame f;
-	if ((rc = prepare_frame(s, cam, stream, &f))) return rc;
-	HIP_TRY(launch_variant(f, rows, s, (uint32_t *)d_rgba, (int64_t)(stride_bytes / 4), nullptr, nullptr,
-	                       false, stream));
-	return HMRM_OK;
+	FrameSlot *slot = nullptr;
+	if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
+	return launch_frame(s, c, f, slot, rows, (uint32_t *)d_rgba, (int64_t)(stride_bytes / 4), nullptr, nullptr, false);
+}
+
+int hmrm_scene_take_capped(const hmrm_scene *scene, void *hip_stream, uint64_t *capped) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
+	if (!s || !capped) return fail(HMRM_E_ARG, "NULL argument");
+	HIP_TRY(hipSetDevice(s->device));
+	std::lock_guard<std::mutex> lk(s->mu);
+	*capped = 0;
+	for (StreamCtx *c : s->ctxs)
+		if (c->stream == (hipStream_t)hip_stream) {
+			HIP_TRY(hipStreamSynchronize(c->stream));
+			unsigned long long n = 0;
+			const int rc = take_capped(c, &n);
+			if (rc) return rc;
+			*capped = n;
+			return n ? noterm(n) : HMRM_OK;
+		}
+	return HMRM_OK; // nothing was ever launched on that stream
 }
 
 double hmrm_last_kernel_ms(void) { return g_last_kernel_ms; }
@@ -588,14 +794,20 @@ double hmrm_bench_kernel_ms(const hmrm_scene *scene, const hmrm_camera *cam, int
 	auto body = [&]() -> int {
 		const size_t W = (size_t)cam->width, H = (size_t)cam->height;
 		HIP_TRY(hipSetDevice(s->device));
+		std::lock_guard<std::mutex> lk(s->mu);
 		int rc = ensure_frame(s, W * H);
 		if (rc) return rc;
+		StreamCtx *c = nullptr;
+		if ((rc = ctx_for(s, s->stream, &c))) return rc;
 		hmrm::DevFrame f;
-		if ((rc = prepare_frame(s, cam, s->stream, &f))) return rc;
+		FrameSlot *slot = nullptr;
+		if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
 		hmrm::RowMap rows{0, cam->height, 0, 0, 1, 0};
+		// (one untimed frame first: the ray queue is allocated on first use)
+		if ((rc = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;
 		HIP_TRY(hipEventRecord(s->ev0, s->stream));
 		for (int i = 0; i < iters; ++i)
-			HIP_TRY(launch_variant(f, rows, s, s->d_frame, (int64_t)W, nullptr, nullptr, false, s->stream));
+			if ((rc = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;
 		HIP_TRY(hipEventRecord(s->ev1, s->stream));
 		HIP_TRY(hipStreamSynchronize(s->stream));
 		float ms = 0.f;
@@ -784,9 +996,12 @@ int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam, int32_t px, 
 	if (!s || !pos || !dir || !entry_d) return fail(HMRM_E_ARG, "NULL argument");
 	if (px < 0 || py < 0 || px >= cam->width || py >= cam->height) return fail(HMRM_E_ARG, "pixel out of range");
 	HIP_TRY(hipSetDevice(s->device));
+	std::lock_guard<std::mutex> lk(s->mu);
 	if ((rc = ensure_stats(s, 8))) return rc;
+	StreamCtx *c = nullptr;
+	if ((rc = ctx_for(s, s->stream, &c))) return rc;
 	hmrm::DevFrame f;
-	if ((rc = prepare_frame(s, cam, s->stream, &f))) return rc;
+	if ((rc = prepare_frame(s, c, cam, &f, nullptr))) return rc;
 	HIP_TRY(hmrm::launch_probe(f, px, py, s->d_entry, s->stream));
 	double host[7];
 	HIP_TRY(hipMemcpyAsync(host, s->d_entry, sizeof host, hipMemcpyDeviceToHost, s->stream));

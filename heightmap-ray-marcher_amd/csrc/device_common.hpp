@@ -178,6 +178,15 @@ struct PixelId {
 	int px, py, lrow;
 	bool live;
 };
+// Frame row of local row `lrow` of the launch's output (contiguous strip or cyclic bands).
+__device__ __forceinline__ int frame_row_of(const RowMap &rows, int lrow) {
+	if (rows.band_rows > 0) {
+		const int band = lrow / rows.band_rows, within = lrow - band * rows.band_rows;
+		return (rows.band_index + band * rows.band_count) * rows.band_rows + within;
+	}
+	return rows.row_begin + lrow;
+}
+
 __device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap &rows, int tiles_y) {
 	// Grid of tiles: x = tile column (fastest, so workgroups still start row by row), y (+ z for
 	// frames taller than 32768 tile rows) = tile row; the rows are rotated so that the costliest
@@ -192,12 +201,7 @@ __device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap
 	PixelId p;
 	p.px = tile_x * kTileW + (wave % kWavesX) * kWaveW + (lane % kWaveW);
 	p.lrow = tile_y * kTileH + (wave / kWavesX) * kWaveH + (lane / kWaveW);
-	if (rows.band_rows > 0) {
-		const int band = p.lrow / rows.band_rows, within = p.lrow - band * rows.band_rows;
-		p.py = (rows.band_index + band * rows.band_count) * rows.band_rows + within;
-	} else {
-		p.py = rows.row_begin + p.lrow;
-	}
+	p.py = frame_row_of(rows, p.lrow);
 	p.live = row_exists && p.px < f.screen_w && p.lrow < rows.local_rows && p.py < f.screen_h;
 	return p;
 }

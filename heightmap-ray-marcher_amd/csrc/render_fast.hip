@@ -31,6 +31,7 @@
 // a window in which it has at least S/2 cells of room ahead.  Values are floats
 // rounded UP (a larger bound is always safe).  Above them: the whole map (thr_max).
 #include "device_common.hpp"
+#include "leap_common.hpp"
 #include "render.hpp"
 
 #pragma clang fp contract(off)
@@ -47,44 +48,10 @@ constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group
 #define HMRM_MIN_LEAP 2
 #endif
 constexpr int kMinLeap = HMRM_MIN_LEAP; // a jump shorter than this is not worth its bookkeeping
-constexpr int kTopLevel = kMipLevels; // whole-map level (thr_max, no load)
 #ifndef HMRM_UP_RATIO
 #define HMRM_UP_RATIO (kLevelStep == 2 ? 4.0 : 2.0)
 #endif
 constexpr double kUpRatio = HMRM_UP_RATIO; // see the level policy in k_render_fast
-
-__device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
-__device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)(unsigned long long)__double_as_longlong(v); }
-__device__ __forceinline__ double f64_from_hi(uint32_t hi) { return __longlong_as_double((long long)((unsigned long long)hi << 32)); }
-
-// Cell coordinate q with trunc(q) == trunc(v / grid_width); v is x - c0.x or -(y - c0.y) with
-// c0.x = c0.y = 0.0 (hmap.cpp:968: v - 0.0 == v for every v, so the subtraction is elided).
-//   GWM 0: grid_width == 1.0   -> q = v
-//   GWM 1: grid_width = 2^k    -> q = v * 2^-k                 (exact reciprocal)
-//   GWM 2: any grid_width      -> q' = v * fl(1/gw), which differs from the correctly rounded
-//          v/gw by < 2^-50 relative.  Unless q' lies within 2^-20 of an integer both truncate to
-//          the same cell (for |q'| >= 2^28 both are far outside any map, whatever they truncate
-//          to); `near` collects that rare case and the caller then divides for real.
-template <int GWM>
-__device__ __forceinline__ double cell_coord_fast(double v, const DevFrame &f, bool &near) {
-	if (GWM == 0) return v;
-	const double q = v * f.inv_grid_width;
-	if (GWM == 2) near = near || !(__builtin_fabs(__builtin_amdgcn_fract(q) - 0.5) < 0.5 - 0x1p-20);
-	return q;
-}
-
-// (int)q exactly as the reference's x86 build evaluates it for the range test of hmap.cpp:1001-
-// 1011, without C++'s undefined behaviour for out-of-range values: v_cvt_i32_f64 truncates
-// toward zero and saturates, so q in (-1,0) gives 0 (inside, as on the CPU), q <= -1 a negative
-// index, |q| >= 2^31 and +-inf give INT_MIN / INT_MAX (outside; cvttsd2si gives INT_MIN: also
-// outside).  Only NaN would differ (0 here, INT_MIN there), and a position cannot be NaN inside
-// the loop: the entry point is checked once, and sums of finite or infinite steps of one sign
-// never produce NaN.
-__device__ __forceinline__ int cvt_i32_sat(double q) {
-	int r;
-	asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(q));
-	return r;
-}
 
 // ---- bilinear quality mode (HMRM_BILINEAR; a build-side addition, not in the reference) ----
 // Same definition, operation for operation, as oracle/hmrm_oracle.c "bilinear quality mode":
@@ -132,65 +99,26 @@ __device__ __forceinline__ uint32_t shade_hit_bilinear(const DevFrame &f, const 
 	return pack_rgba(ch[0], ch[1], ch[2]);
 }
 
-// Exact-stepping state of one coordinate inside its current binade.
-struct Axis {
-	double delta;  // p_{k+1} - p_k for every p of the binade (valid iff key matches)
-	double lim;    // binade boundary the coordinate is moving towards
-	double rdel;   // ~1/delta (signed); (lim - p) * rdel estimates the steps left
-	uint32_t key;  // sign+exponent bits (hi32 >> 20) the above was measured for
-};
-
-// Measure delta at p (see file header) from TWO real steps.  Off a rounding tie the
-// increment is the same for every p of the binade.  On an exact tie (s = q*u + u/2)
-// round-to-even makes every result an even multiple of u, so from the first step on
-// the increment is constant as well (q or q+1 by the parity of q); only a start value
-// of the wrong parity steps differently once -- which shows as two unequal increments
-// and is rejected here (the next group of real steps lands on the steady parity).
-// Invalid (key = ~0) also when the two steps leave the binade or change sign, or p is
-// tiny / non-finite.
-__device__ __forceinline__ void axis_refresh(Axis &a, double p, double s) {
-	// straight-line on purpose (bitwise tests, selects): a wave runs this whenever any lane
-	// crosses a binade, so exec-mask branches here would cost every lane of the wave
-	const double p1 = p + s, p2 = p1 + s;
-	const uint32_t hp = hi32(p), hp1 = hi32(p1), hp2 = hi32(p2);
-	const uint32_t e = (hp >> 20) & 0x7ffu;
-	const double d = p1 - p;                  // exact: multiples of u, |d| < 2^53 u
-	const int ok = (int)((((hp ^ hp1) | (hp ^ hp2)) >> 20) == 0u) & (int)(e - 128u <= 1772u) & (int)((p2 - p1) == d);
-	a.key = ok ? (hp >> 20) : 0xffffffffu;
-	a.delta = d;
-	// |p| grows (d has p's sign): the limit is 2^(E+1), else 2^E; either way with p's sign.
-	// One integer add on the high word (E <= 1900, no overflow into the sign).
-	const uint32_t away = (((hi32(d) ^ hp) >> 31) ^ 1u) << 20;
-	const double lim = f64_from_hi((hp & 0xfff00000u) + away);
-	const bool still = d == 0.0;              // the coordinate never moves (s == 0 or absorbed): unlimited room
-	a.lim = still ? p + 1.0 : lim;
-	a.rdel = still ? 0x1p40 : __builtin_amdgcn_rcp(d);
-}
-
-// p_n = p + n*delta is trustworthy iff it is still in p's binade with the same sign,
-// and -- when the coordinate moves -- not exactly on a binade boundary (moving towards
-// zero, the step that produced it could have rounded on the finer grid below 2^E).
-__device__ __forceinline__ bool axis_landing_ok(const Axis &a, double pn) {
-	// (bitwise on purpose: one straight-line expression instead of a chain of exec-mask branches)
-	const uint32_t h = hi32(pn);
-	const int same_binade = (h >> 20) == a.key ? 1 : 0;
-	const int off_boundary = ((h & 0xfffffu) | lo32(pn)) != 0u ? 1 : 0;
-	const int still = a.delta == 0.0 ? 1 : 0;
-	return (same_binade & (still | off_boundary)) != 0;
-}
-
 } // namespace
 
 #ifndef HMRM_MIN_WAVES
 #define HMRM_MIN_WAVES 1
 #endif
-template <int PROJ, bool STATS, int GWM, bool LEAP, bool BILINEAR>
-__global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(const DevFrame f, const RowMap rows,
+#ifdef HMRM_WAVES_PER_EU
+#define HMRM_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(HMRM_WAVES_PER_EU, HMRM_WAVES_PER_EU)))
+#else
+#define HMRM_OCCUPANCY_ATTR
+#endif
+template <int PROJ, bool STATS, int GWM, bool LEAP, bool BILINEAR, bool QUEUE>
+__global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR void k_render_fast(const DevFrame f, const RowMap rows,
                                                      const double *__restrict__ thr,
                                                      const uint32_t *__restrict__ cmap,
                                                      uint32_t *__restrict__ out, int64_t out_stride_px,
-                                                     int tiles_y, StatsOut st) {
+                                                     int tiles_y, StatsOut st, const RayQueue q) {
 	const PixelId pid = pixel_of_lane(f, rows, tiles_y);
+#ifdef HMRM_EXP_SKIP_ROWS_BELOW
+	if (pid.py < HMRM_EXP_SKIP_ROWS_BELOW) return; // experiment only: what do the rows above cost in the mix?
+#endif
 	const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull; // tools-only timing
 	unsigned long long my_steps = 0;
 	uint32_t my_hit = 0, my_cap = 0;
@@ -208,6 +136,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 
 		uint32_t rgba = 0;
 		bool real_hit = false;
+		bool queued = false; // handed over to the ray-queue kernel, which then writes this pixel
 
 		if (!(d == __builtin_huge_val()) && !(d < 0.0)) { // intersection(), AABB.cpp:33-44
 			double x = ray.px + d * ray.dx;
@@ -220,7 +149,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 			const double sy = f.step_dist * ray.dy;
 			const double sz = f.step_dist * ray.dz;
 			const unsigned wlim = (unsigned)f.map_w, hlim = (unsigned)f.map_h;
-			int budget = f.step_cap > 0x7fffffff ? 0x7fffffff : (int)f.step_cap;
+			const int budget0 = f.step_cap > 0x7fffffff ? 0x7fffffff : (int)f.step_cap;
+			int budget = budget0; // every step taken or leaped comes off it: steps so far = budget0 - budget
 			// (int)NaN is INT_MIN on the reference's CPU: the first range test fails, the ray misses
 			const bool entry_nan = x != x || y != y;
 
@@ -251,7 +181,15 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 			// branch any of its lanes takes, and exec-mask juggling per `if` costs as much as
 			// the arithmetic it guards.  Values are computed for all lanes and selected.
 			bool done = entry_nan;
-			while (!done) {
+			// Two-pass split (QUEUE): after `pass1_trips` trips a ray still marching is appended to the
+			// ray queue and finished by k_march_queue (march_queue.hip), which spends several lanes per ray
+			// and spreads the stragglers of one tile over the whole chip; its state is the position of
+			// the next untested step, the step budget and the level.  If the queue is full the ray just
+			// carries on here.
+			int trip = 0;
+			int trip_limit = (QUEUE && q.pass1_trips > 0) ? q.pass1_trips : 0x7fffffff;
+			for (;;) {
+			for (; !done && trip < trip_limit; ++trip) {
 				bool skip_group = false;
 				bool dg_attempted = false; // diagnostics only
 				// ---------------------------------------------------------- leap
@@ -373,7 +311,6 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 							dg_x3 += (ok && lev == 3) ? (unsigned)n : 0u;
 						}
 						if (STATS) {
-							my_steps += ok ? (unsigned)n : 0u;
 							dg_leaped += ok ? (unsigned)n : 0u;
 							dg_leaps += ok ? 1u : 0u;
 						}
@@ -517,7 +454,6 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 					}
 					const int taken = first + (hit ? 1 : 0); // loads the reference executed in this group
 					budget -= taken;
-					if (STATS) my_steps += (unsigned)taken;
 					done = first < kGroup;
 					if (hit) {
 						if (BILINEAR) {
@@ -547,7 +483,6 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 						if (!((unsigned)gx < wlim && (unsigned)gy < hlim)) { done = true; break; }
 						if (budget <= 0) { my_cap = 1; done = true; break; }
 						--budget;
-						if (STATS) my_steps += 1;
 						const int c = gy * f.map_w + gx;
 						Bil b{};
 						double t;
@@ -572,12 +507,36 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) void k_render_fast(c
 				y = Y[kGroup - 1] + sy;
 				z = Z[kGroup - 1] + sz;
 			}
+			if (!QUEUE || done) break;
+			// hand-over: the lanes of the wave still marching arrive here together (same trip count);
+			// one atomic per wave reserves their slots
+			const unsigned long long arriving = __ballot(true);
+			const int lane = (int)(threadIdx.x & 63u);
+			const unsigned rank = (unsigned)__popcll(arriving & ((1ull << lane) - 1ull));
+			unsigned first_slot = 0;
+			if (rank == 0) first_slot = atomicAdd(q.count, (unsigned)__popcll(arriving));
+			first_slot = (unsigned)__builtin_amdgcn_readfirstlane((int)first_slot); // (the lowest arriving lane has rank 0)
+			const unsigned slot = first_slot + rank;
+			if (slot < q.capacity) {
+				q.x[slot] = x;
+				q.y[slot] = y;
+				q.z[slot] = z;
+				q.px[slot] = pid.px;
+				q.lrow[slot] = pid.lrow;
+				q.budget[slot] = budget;
+				q.lev[slot] = lev;
+				queued = true;
+				break;
+			}
+			trip_limit = 0x7fffffff; // queue full: finish here
+			}
+			if (STATS) my_steps = queued ? 0ull : (unsigned long long)(unsigned)(budget0 - budget);
 		}
 
-		if (!real_hit) rgba = shade_miss(f, ray.dz);
-		else my_hit = 1;
-		out[(int64_t)pid.lrow * out_stride_px + pid.px] = rgba;
-		if (STATS && st.steps_per_pixel)
+		if (real_hit) my_hit = 1;
+		else if (!queued) rgba = shade_miss(f, ray.dz);
+		if (!queued) out[(int64_t)pid.lrow * out_stride_px + pid.px] = rgba;
+		if (STATS && st.steps_per_pixel && !queued)
 			st.steps_per_pixel[(int64_t)pid.py * f.screen_w + pid.px] =
 			    f.diag_mode == 1 ? ((dg_attempts > 0xffffu ? 0xffffu : dg_attempts) << 16) |
 			                       (dg_groups > 0xffffu ? 0xffffu : dg_groups)
@@ -701,56 +660,59 @@ hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *
 template <int PROJ, bool STATS, int GWM, bool LEAP>
 static void launch_one(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
                        uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid, int tiles_y,
-                       hipStream_t stream) {
+                       const RayQueue &q, hipStream_t stream) {
 	if (f.sampling == 1)
-		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, true>), grid, dim3(kBlockThreads), 0, stream, f, rows,
-		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, true, false>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q);
+	else if (LEAP && q.pass1_trips > 0)
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, false, LEAP>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q);
 	else
-		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, false>), grid, dim3(kBlockThreads), 0, stream, f, rows,
-		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, false, false>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q);
 }
 
 template <int PROJ, bool STATS, int GWM>
 static void launch_leap(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
-                        int tiles_y, hipStream_t stream) {
-	if (leap) launch_one<PROJ, STATS, GWM, true>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
-	else launch_one<PROJ, STATS, GWM, false>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+                        int tiles_y, const RayQueue &q, hipStream_t stream) {
+	if (leap) launch_one<PROJ, STATS, GWM, true>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream);
+	else launch_one<PROJ, STATS, GWM, false>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream);
 }
 
 template <int PROJ, bool STATS>
 static void launch_gwm(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                        const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
-                       int tiles_y, hipStream_t stream) {
+                       int tiles_y, const RayQueue &q, hipStream_t stream) {
 	switch (f.grid_mode) {
-	case 0: launch_leap<PROJ, STATS, 0>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
-	case 1: launch_leap<PROJ, STATS, 1>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
-	default: launch_leap<PROJ, STATS, 2>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	case 0: launch_leap<PROJ, STATS, 0>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
+	case 1: launch_leap<PROJ, STATS, 1>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
+	default: launch_leap<PROJ, STATS, 2>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
 	}
 }
 
 template <bool STATS>
 static void launch_proj(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
-                        int tiles_y, hipStream_t stream) {
+                        int tiles_y, const RayQueue &q, hipStream_t stream) {
 	switch (f.projection) {
-	case 1: launch_gwm<1, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
-	case 2: launch_gwm<2, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
-	default: launch_gwm<3, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	case 1: launch_gwm<1, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
+	case 2: launch_gwm<2, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
+	default: launch_gwm<3, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
 	}
 }
 
 hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr,
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
-                              bool leap, hipStream_t stream) {
+                              bool leap, const RayQueue &q, hipStream_t stream) {
 	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
 	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
 	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
 	const dim3 grid((unsigned)tiles_x, (unsigned)(tiles_y < 32768 ? tiles_y : 32768), (unsigned)((tiles_y + 32767) / 32768));
 	StatsOut st{d_counters, d_steps, d_entry};
-	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
-	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream);
+	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream);
 	return hipGetLastError();
 }
 

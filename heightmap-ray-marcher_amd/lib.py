@@ -102,6 +102,8 @@ def _load():
         "hmrm_render": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t]),
         "hmrm_render_cycle": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, i32, i32]),
         "hmrm_render_rows_device": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, i32, i32, i32, i32, i32, vp]),
+        "hmrm_scene_take_capped": (C.c_int, [vp, vp, C.POINTER(C.c_uint64)]),
+        "hmrm_debug_reload_env": (C.c_int, [vp]),
         "hmrm_band_local_rows": (i32, [i32, i32, i32, i32]),
         "hmrm_render_stats": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(Stats), vp, vp]),
         "hmrm_debug_ray": (C.c_int, [vp, C.POINTER(Camera), i32, i32, dp, dp, dp]),
@@ -148,6 +150,21 @@ def _load():
 lib, EXPORTED_SYMBOLS = _load()
 
 
+# Device + launch sources: a PMC summary (profiles/traffic.json) is only valid for the kernel it was
+# collected on, so it carries this hash and bench.py refuses one that does not match the tree.
+KERNEL_SOURCES = ("render_fast.hip", "render.hip", "device_common.hpp", "frame.hpp", "render.hpp", "api.cpp",
+                  "camera.cpp", "Makefile")
+
+
+def kernel_src_sha() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def last_error() -> str:
     return (lib.hmrm_last_error() or b"").decode("utf-8", "replace")
 
@@ -173,6 +190,16 @@ def set_device(i: int):
     _check(lib.hmrm_set_device(int(i)))
 
 
+# The library reads its environment knobs once per scene.  Tests and tools flip them
+# on live scenes, so the Python wrappers re-read them when one changed since the scene last looked.
+_ENV_KNOBS = ("HMRM_KERNEL", "HMRM_STEP_CAP", "HMRM_TILE_ORDER", "HMRM_DIAG_ITERS", "HMRM_MIN_LEVEL",
+              "HMRM_PASS1_TRIPS")
+
+
+def _env_snapshot():
+    return tuple(os.environ.get(k) for k in _ENV_KNOBS)
+
+
 class Scene:
     """Device-resident height + colour maps (replaces the globals filled at hmap.cpp:314-353)."""
 
@@ -188,13 +215,21 @@ class Scene:
         self.map_h, self.map_w = int(h_rgb.shape[0]), int(h_rgb.shape[1])
         self.params = params
         self._h = C.c_void_p()
+        self._env = _env_snapshot()
         _check(lib.hmrm_scene_create(_ptr(h_rgb), _ptr(c_rgba), self.map_w, self.map_h,
                                      C.byref(params), C.byref(self._h)))
+
+    def _sync_env(self):
+        now = _env_snapshot()
+        if now != getattr(self, "_env", None):
+            _check(lib.hmrm_debug_reload_env(self._h))
+            self._env = now
 
     @classmethod
     def _adopt(cls, handle, map_w, map_h, params):
         s = cls.__new__(cls)
         s._h, s.map_w, s.map_h, s.params = handle, map_w, map_h, params
+        s._env = _env_snapshot()
         return s
 
     def close(self):
@@ -215,6 +250,7 @@ class Scene:
 
     def render(self, cam: Camera) -> np.ndarray:
         """One full frame (hmap.cpp:978-1058 at `cycle 1`) -> HxWx4 uint8."""
+        self._sync_env()
         fb = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
         _check(lib.hmrm_render(self._h, C.byref(cam), _ptr(fb), cam.width * 4))
         return fb
@@ -222,9 +258,11 @@ class Scene:
     def render_cycle(self, cam: Camera, framebuf: np.ndarray, cycle: int, cycle_period: int):
         """Progressive refresh (hmap.cpp:976-983): rewrites pixels p = cycle (mod cycle_period) in place."""
         assert framebuf.dtype == np.uint8 and framebuf.shape == (cam.height, cam.width, 4) and framebuf.flags.c_contiguous
+        self._sync_env()
         _check(lib.hmrm_render_cycle(self._h, C.byref(cam), _ptr(framebuf), cam.width * 4, cycle, cycle_period))
 
     def render_stats(self, cam: Camera, per_pixel=False, allow_capped=False):
+        self._sync_env()
         fb = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
         st = Stats()
         steps = np.empty((cam.height, cam.width), dtype=np.uint32) if per_pixel else None
@@ -236,9 +274,18 @@ class Scene:
 
     def render_rows_device(self, cam: Camera, d_ptr: int, stride_bytes: int, row_begin=0, row_end=0,
                            band_rows=0, band_index=0, band_count=1, stream: int = 0):
+        self._sync_env()
         _check(lib.hmrm_render_rows_device(self._h, C.byref(cam), C.c_void_p(d_ptr), stride_bytes,
                                            row_begin, row_end, band_rows, band_index, band_count,
                                            C.c_void_p(stream)))
+
+    def take_capped(self, stream: int = 0, allow_capped=False) -> int:
+        """Rays of the launches enqueued on `stream` that reached the step cap since the last call
+        (waits for the stream); raises HMRM_E_NOTERM for a non-zero count unless allowed."""
+        n = C.c_uint64()
+        _check(lib.hmrm_scene_take_capped(self._h, C.c_void_p(stream), C.byref(n)),
+               allow=(HMRM_E_NOTERM,) if allow_capped else ())
+        return int(n.value)
 
     def debug_ray(self, cam: Camera, px: int, py: int):
         pos, dirv, d = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
@@ -246,6 +293,7 @@ class Scene:
         return np.array(pos[:]), np.array(dirv[:]), d.value
 
     def bench_kernel_ms(self, cam: Camera, iters: int) -> float:
+        self._sync_env()
         ms = lib.hmrm_bench_kernel_ms(self._h, C.byref(cam), int(iters))
         if ms < 0:
             raise HmrmError(HMRM_E_DEVICE, last_error())

@@ -150,6 +150,13 @@ int hmrm_render_rows_device(const hmrm_scene *scene, const hmrm_camera *cam,
                             int32_t band_rows, int32_t band_index, int32_t band_count,
                             void *hip_stream);
 
+/* hmrm_render_rows_device does not wait for its launch, so it cannot report rays stopped by the
+ * step cap (HMRM_E_NOTERM of hmrm_render; the reference's loop would not terminate for them,
+ * hmap.cpp:1000).  This call waits for `hip_stream`, stores in *capped how many rays of the launches
+ * enqueued on it through this scene reached the cap since the last call, and returns
+ * HMRM_E_NOTERM when that is not zero. */
+int hmrm_scene_take_capped(const hmrm_scene *scene, void *hip_stream, uint64_t *capped);
+
 /* Rows the strip buffer of one rank must hold in cyclic-band mode (full bands). */
 int32_t hmrm_band_local_rows(int32_t height, int32_t band_rows, int32_t band_index, int32_t band_count);
 
@@ -174,6 +181,10 @@ int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam,
  * sin(ha) per column, then sin(va) and cos(va) per row (Spherical.cpp:18-25). */
 int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params,
                      int32_t map_w, int32_t map_h, double *out25, double *tables);
+
+/* The environment knobs (HMRM_KERNEL, HMRM_STEP_CAP, ...) are read once, when a
+ * scene is created; this re-reads them for a live scene (tests and tools switch kernel variants). */
+int hmrm_debug_reload_env(hmrm_scene *scene);
 
 /* Time of the most recent render kernel launch on this thread, measured with
  * HIP events on the launch stream (ms); <0 if none. Only valid after

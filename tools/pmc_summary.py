@@ -1,40 +1,126 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 outputs under a directory tree into one text + traffic.json.
+"""Summarise rocprofv3 outputs under a directory tree into one text file + profiles/traffic.json.
 
 usage: pmc_summary.py <gpurun_out/prof_dir> <workload> <out_prefix>
-Reads every */*_counter_collection.csv and */*_kernel_stats.csv below the directory,
-averages counters over the dispatches of kernels whose name contains 'k_render'.
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  Per MI355X_MICROARCH.md
-(HBM section) FETCH_SIZE under-counts wide coalesced streams by 2x on gfx950 and is
-uncalibrated for other access widths; this kernel's reads are 8-byte gathers, so the
-raw figure is kept and the x2 bound is listed next to it."""
-import collections, csv, glob, json, os, sys
 
+Reads every */*_counter_collection.csv, *_kernel_trace.csv and *_kernel_stats.csv below the directory.
+A frame is one launch of each render kernel of the product (k_render_fast, and k_march_queue when the
+two-pass split is on); counters are averaged per dispatch and kernel, then summed over the kernels of a
+frame.  The instrumented instantiations (STATS = true) are left out.
+
+Units and corrections (MI355X_MICROARCH.md, HBM / rocprofv3 sections, and tools/valu_calib.hip):
+  * FETCH_SIZE / WRITE_SIZE are in KiB.  FETCH_SIZE counts 64 B per request and reads half the bytes of
+    wide (16 B per lane) coalesced streams on gfx950; this kernel's reads are 4- and 8-byte gathers, an
+    uncalibrated width, so the raw figure is kept and twice the figure is listed as an upper bound.
+  * SQ_ACTIVE_INST_VALU adds one unit (a quad-cycle) per VALU instruction whatever its class and four
+    per fp64 transcendental (calibration: profiles/r02_valu_calibration.txt), so x4 it is the pipe
+    occupancy only if every instruction held the pipe for 4 cycles.  The weighted figure prices the
+    classes as measured with 8 waves per SIMD: 4 cycles for the fp64 add/mul/fma/compare/convert class,
+    16 for fp64 rcp/sqrt, 2.3 for the rest (32-bit integer / logic / select / move).
+  * lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU).
+The JSON entry carries the hash of the kernel sources (lib.kernel_src_sha) so that bench.py can refuse
+numbers collected on another kernel."""
+import collections, csv, glob, importlib, json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 root, workload, out_prefix = sys.argv[1], sys.argv[2], sys.argv[3]
-counters = collections.defaultdict(list)
+
+SIMDS = 1024
+PEAK_CLOCK_HZ = 2.4e9
+CYC_F64, CYC_TRANS64, CYC_OTHER = 4.0, 16.0, 2.3
+
+
+def product_kernel(name):
+    if "k_render_fast<" in name or "k_march_queue<" in name or "k_render<" in name:
+        args = name.split("<", 1)[1]
+        fields = [a.strip() for a in args.split(">")[0].split(",")]
+        return len(fields) < 2 or fields[1] != "true"  # STATS is the second template argument
+    return False
+
+
+def short(name):
+    return name.split("(")[0].replace("void hmrm::", "")
+
+
+per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True):
     per_dispatch = collections.defaultdict(float)
+    names = {}
     for r in csv.DictReader(open(f)):
-        if "k_render" in r["Kernel_Name"] and "Lb1E" not in r["Kernel_Name"].split("k_render")[1][:14]:
+        if product_kernel(r["Kernel_Name"]):
             per_dispatch[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
-    for (_, name), v in per_dispatch.items():
-        counters[name].append(v)
-lines = []
-avg = {k: sum(v) / len(v) for k, v in counters.items()}
-for k in sorted(avg):
-    lines.append(f"{k:24s} {avg[k]:18.1f}  (mean of {len(counters[k])} dispatches)")
-stats = []
-for f in glob.glob(os.path.join(root, "**", "*_kernel_stats.csv"), recursive=True):
-    stats.append(open(f).read())
+            names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+    for (disp, cname), v in per_dispatch.items():
+        per_kernel[names[disp]][cname].append(v)
+
+durations = collections.defaultdict(list)
+for f in glob.glob(os.path.join(root, "trace", "**", "*_kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if product_kernel(r["Kernel_Name"]):
+            durations[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+
+lines, frame = [], collections.defaultdict(float)
+for k in sorted(per_kernel):
+    lines.append(f"== {k}")
+    for c in sorted(per_kernel[k]):
+        v = per_kernel[k][c]
+        m = sum(v) / len(v)
+        frame[c] += m
+        lines.append(f"   {c:28s} {m:18.1f}  (mean of {len(v)} dispatches)")
+frame_ns = 0.0
+for k in sorted(durations):
+    v = durations[k]
+    frame_ns += sum(v) / len(v)
+    lines.append(f"== {k}: {len(v)} launches in the kernel trace, mean {sum(v) / len(v) / 1e3:.2f} us, "
+                 f"min {min(v) / 1e3:.2f}, max {max(v) / 1e3:.2f}")
+
+entry = {"kernels": sorted(per_kernel), "counters_per_frame": dict(sorted(frame.items())),
+         "kernel_us_per_frame_rocprof": frame_ns / 1e3 if frame_ns else None}
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HMRM_NO_TORCH_PRELOAD", "1")  # (only the source hash is needed, not torch)
+entry["kernel_src_sha"] = importlib.import_module("heightmap-ray-marcher_amd.lib").kernel_src_sha()
+try:
+    entry["git_commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                         text=True).stdout.strip() or None
+except OSError:
+    entry["git_commit"] = None
+
+if "FETCH_SIZE" in frame and "WRITE_SIZE" in frame:
+    fetch, write = frame["FETCH_SIZE"] * 1024.0, frame["WRITE_SIZE"] * 1024.0
+    entry.update(hbm_bytes_per_launch=fetch + write, fetch_bytes_raw=fetch, write_bytes=write,
+                 fetch_bytes_if_undercounted_2x=2 * fetch)
+    lines.append(f"HBM traffic per frame: FETCH {fetch / 1e6:.1f} MB (raw; <= {2 * fetch / 1e6:.1f} MB if the 2x "
+                 f"under-count of wide streams applied) + WRITE {write / 1e6:.1f} MB")
+if "SQ_INSTS_VALU" in frame:
+    n = frame["SQ_INSTS_VALU"]
+    f64 = sum(frame.get("SQ_INSTS_VALU_" + c, 0.0) for c in ("ADD_F64", "MUL_F64", "FMA_F64"))
+    trans = frame.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+    have_classes = "SQ_INSTS_VALU_ADD_F64" in frame
+    valu = {"insts": n, "f64_add_mul_fma": f64 if have_classes else None, "f64_trans": trans if have_classes else None,
+            "busy_cycles_upper": 4.0 * frame.get("SQ_ACTIVE_INST_VALU", n)}
+    if have_classes:
+        # compares, conversions, min/max and moves of fp64 values are not in the three arithmetic
+        # counters but cost the fp64 rate: priced through the calibrated mix of the kernel's own ISA is
+        # not possible from counters, so they are counted at the cheaper rate (a LOWER bound)
+        valu["busy_cycles_weighted"] = CYC_F64 * f64 + CYC_TRANS64 * trans + CYC_OTHER * max(n - f64 - trans, 0.0)
+    entry["valu"] = valu
+    lines.append(f"VALU per frame: {n:.0f} wave-instructions; fp64 add/mul/fma {f64:.0f}, fp64 rcp/sqrt {trans:.0f}")
+if "SQ_THREAD_CYCLES_VALU" in frame and "SQ_ACTIVE_INST_VALU" in frame:
+    entry["lane_util"] = frame["SQ_THREAD_CYCLES_VALU"] / (64.0 * frame["SQ_ACTIVE_INST_VALU"])
+    lines.append(f"lane utilisation (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU): {entry['lane_util']:.3f}")
+if frame_ns and "valu" in entry:
+    simd_cycles = SIMDS * frame_ns * 1e-9 * PEAK_CLOCK_HZ
+    lines.append(f"SIMD-cycles available per frame at 2.4 GHz over {frame_ns / 1e3:.1f} us: {simd_cycles:.3e}; "
+                 f"VALU busy: upper {entry['valu']['busy_cycles_upper'] / simd_cycles:.3f}"
+                 + (f", weighted {entry['valu']['busy_cycles_weighted'] / simd_cycles:.3f}"
+                    if entry['valu'].get('busy_cycles_weighted') else ""))
+
+stats = [open(f).read() for f in glob.glob(os.path.join(root, "**", "*_kernel_stats.csv"), recursive=True)]
 text = "\n".join(lines) + "\n\n" + "\n".join(stats)
 open(out_prefix + ".txt", "w").write(text)
 print(text)
-if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
-    fetch, write = avg["FETCH_SIZE"] * 1024.0, avg["WRITE_SIZE"] * 1024.0
-    tj = os.path.join(os.path.dirname(out_prefix), "traffic.json")
-    data = json.load(open(tj)) if os.path.exists(tj) else {}
-    data[workload] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_raw": fetch, "write_bytes": write,
-                      "fetch_bytes_if_undercounted_2x": 2 * fetch,
-                      "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per k_render launch; "
-                              "FETCH_SIZE kept raw: reads are 8-byte gathers (uncalibrated width on gfx950)"}
-    json.dump(data, open(tj, "w"), indent=1, sort_keys=True)
+tj = os.path.join(os.path.dirname(out_prefix), "traffic.json")
+data = json.load(open(tj)) if os.path.exists(tj) else {}
+entry["source"] = os.path.basename(out_prefix) + ".txt"
+data[workload] = entry
+json.dump(data, open(tj, "w"), indent=1, sort_keys=True)

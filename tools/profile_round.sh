@@ -3,21 +3,29 @@
 # PMC passes (separate runs, counters only with --kernel-trace), A/B of the kernel variants and the
 # diagnostic tools.  Everything lands under gpurun_out/prof_<tag>/ ; summarise afterwards with
 #   python tools/pmc_summary.py gpurun_out/prof_<tag> C3 profiles/<tag>_C3_rocprof
-# usage: tools/profile_round.sh <tag>
+# usage: tools/profile_round.sh <tag> [quick]
 set -u
 tag=${1:-round}
+quick=${2:-}
 out=gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$out"; mkdir -p "$out"
 timeout -k 10 300 python bench.py > "$out/bench.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --no-cpu-baseline > "$out/bench_under_rocprof.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum --kernel-trace --output-format csv -d "$out/fetch" -- python tools/prof_run.py C3 leap 10 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d "$out/write" -- python tools/prof_run.py C3 leap 10 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d "$out/sq" -- python tools/prof_run.py C3 leap 10 > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-trace --output-format csv -d "$out/sq2" -- python tools/prof_run.py C3 leap 10 > /dev/null 2>&1
+pmc() { # <dir> <counters...>
+	d=$1; shift
+	rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/$d" -- python tools/prof_run.py C3 leap 10 > /dev/null 2>&1
+}
+pmc fetch FETCH_SIZE TCC_HIT_sum
+pmc write WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
+pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
+pmc sq2 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
+pmc sq3 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64
+if [ -z "$quick" ]; then
 timeout -k 10 400 python tools/variants_bench.py C3 C3h C2 C5 C4 2>&1 | grep -v "amdgpu.ids" > "$out/variants.log"
 timeout -k 10 300 python tools/iter_map.py C3 2>&1 | grep -v amdgpu.ids > "$out/iter_map.log"
 timeout -k 10 300 python tools/e2e_time.py C3 2>&1 | grep -v amdgpu.ids > "$out/e2e.log"
 timeout -k 10 300 python tools/experiments.py 2>&1 | grep -v amdgpu.ids | grep leap > "$out/experiments.log"
 timeout -k 10 300 python tools/gw_bench.py 2>&1 | grep -v amdgpu.ids > "$out/gw_bench.log"
+fi
 grep "^{" "$out/bench.log" | cut -c1-300
