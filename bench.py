@@ -273,7 +273,7 @@ def main():
             "hbm": {"achieved": (traffic / kernel_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None},
             "lane_util": (pmc or {}).get("lane_util"),
-            "kernel": "k_render_fast (+ k_march_queue)", "kernel_ms": kernel_ms,
+            "kernel": "k_render_fast", "kernel_ms": kernel_ms,
             "kernel_ray_steps_per_s": frame_steps / kernel_s,
             # BASELINE.md's nominal figure: bytes the REFERENCE's loop would move for this frame over the
             # measured duration.  Not executed traffic (the loads are skipped), hence not a fraction of a peak.

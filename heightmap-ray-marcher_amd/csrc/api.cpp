@@ -55,7 +55,6 @@ struct Knobs {
 	bool tile_order = true;              // HMRM_TILE_ORDER=0 -> row-major launch order
 	int diag_mode = 0;                   // HMRM_DIAG_ITERS (tools)
 	int min_level = -1;                  // HMRM_MIN_LEVEL (tools)
-	int pass1_trips = 24;                // HMRM_PASS1_TRIPS: loop trips before a ray is handed to the ray-queue kernel; 0 = single pass
 };
 
 Knobs read_knobs() {
@@ -72,10 +71,6 @@ Knobs read_knobs() {
 	if (const char *s = getenv("HMRM_DIAG_ITERS")) k.diag_mode = atoi(s);
 	if (const char *s = getenv("HMRM_MIN_LEVEL"))
 		if (s[0] >= '0' && s[0] < '0' + hmrm::kMipLevels) k.min_level = s[0] - '0';
-	if (const char *s = getenv("HMRM_PASS1_TRIPS")) {
-		const int v = atoi(s);
-		if (v >= 0) k.pass1_trips = v;
-	}
 	return k;
 }
 
@@ -103,17 +98,11 @@ struct FrameSlot {
 };
 
 // Everything a launch mutates, per HIP stream: launches on different streams of one scene never
-// share a table, a queue or a counter (hmrm_render_rows_device takes the caller's stream).
+// share a table or a counter (hmrm_render_rows_device takes the caller's stream).
 struct StreamCtx {
 	hipStream_t stream = nullptr;
 	uint64_t stamp = 0;
 	FrameSlot slots[kFrameSlots];
-	// ray queue of the two-pass march (frame.hpp RayQueue), grown on demand
-	double *q_pos = nullptr;  // x | y | z
-	int32_t *q_int = nullptr; // px | lrow | budget | lev
-	uint32_t q_capacity = 0;
-	uint32_t *q_count = nullptr; // two counters, used alternately: a frame's second pass zeroes the other one
-	int q_parity = 0;
 	// [0] steps [1] hits [2] capped rays (cumulative, never reset) [4..7] traversal diagnostics
 	unsigned long long *d_counters = nullptr;
 	unsigned long long capped_seen = 0; // value of [2] the host has already reported
@@ -163,9 +152,6 @@ void destroy_ctx(StreamCtx *c) {
 		if (sl.h_tables) (void)hipHostFree(sl.h_tables);
 		if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
 	}
-	if (c->q_pos) (void)hipFree(c->q_pos);
-	if (c->q_int) (void)hipFree(c->q_int);
-	if (c->q_count) (void)hipFree(c->q_count);
 	if (c->d_counters) (void)hipFree(c->d_counters);
 	delete c;
 }
@@ -192,10 +178,8 @@ int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 	c->stream = stream;
 	c->stamp = ++s->clock;
 	hipError_t e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMalloc((void **)&c->q_count, 2 * sizeof(uint32_t));
 	// (zeroed on the scene's stream and waited for: the caller's stream may be anything)
 	if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s->stream);
-	if (e == hipSuccess) e = hipMemsetAsync(c->q_count, 0, 2 * sizeof(uint32_t), s->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
 	if (e != hipSuccess) {
 		destroy_ctx(c);
@@ -203,22 +187,6 @@ int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 	}
 	s->ctxs.push_back(c);
 	*out = c;
-	return HMRM_OK;
-}
-
-// Ray queue of at least `want` entries (frame.hpp RayQueue).  Growing it happens between frames of
-// this stream only, after the stream has drained.
-int ensure_queue(StreamCtx *c, uint32_t want) {
-	if (want <= c->q_capacity) return HMRM_OK;
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	if (c->q_pos) (void)hipFree(c->q_pos);
-	if (c->q_int) (void)hipFree(c->q_int);
-	c->q_pos = nullptr;
-	c->q_int = nullptr;
-	c->q_capacity = 0;
-	HIP_TRY(hipMalloc((void **)&c->q_pos, (size_t)want * 3 * sizeof(double)));
-	HIP_TRY(hipMalloc((void **)&c->q_int, (size_t)want * 4 * sizeof(int32_t)));
-	c->q_capacity = want;
 	return HMRM_OK;
 }
 
@@ -368,7 +336,7 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 }
 
 // One frame (or row strip) on the context's stream.  Kernel variant: "leap" (default; speculative
-// groups + exact leaps, two passes), "group" (speculative groups only), "simple" (the literal
+// groups + exact leaps), "group" (speculative groups only), "simple" (the literal
 // one-step-at-a-time loop, kept for A/B runs and as an in-library cross-check).  All produce
 // identical pixels and counts.
 int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const FrameSlot *slot, const hmrm::RowMap &rows,
@@ -381,34 +349,8 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const Fra
 		return HMRM_OK;
 	}
 	const bool leap = s->knobs.kernel != 1;
-	hmrm::RayQueue q{};
-	const bool two_pass = leap && f.sampling == 0 && s->knobs.pass1_trips > 0 && f.diag_mode == 0;
-	if (two_pass) {
-		// room for a quarter of the launch's rays (at least 64 Ki): more than ever queue up in
-		// practice, and a full queue only means the surplus finishes in the first pass
-		const int64_t px = (int64_t)f.screen_w * rows.local_rows;
-		const uint32_t want = (uint32_t)std::min<int64_t>(std::max<int64_t>(px / 4, 1 << 16), (int64_t)1 << 26);
-		const int rc = ensure_queue(c, want);
-		if (rc) return rc;
-		const size_t n = c->q_capacity;
-		q.x = c->q_pos;
-		q.y = c->q_pos + n;
-		q.z = c->q_pos + 2 * n;
-		q.px = c->q_int;
-		q.lrow = c->q_int + n;
-		q.budget = c->q_int + 2 * n;
-		q.lev = c->q_int + 3 * n;
-		q.count = c->q_count + c->q_parity;
-		q.capacity = c->q_capacity;
-		q.pass1_trips = s->knobs.pass1_trips;
-	}
 	HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters,
-	                                 d_steps, d_entry, stats, leap, q, c->stream));
-	if (two_pass) {
-		HIP_TRY(hmrm::launch_march_queue(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters,
-		                                 d_steps, stats, q, c->q_count + (c->q_parity ^ 1), c->stream));
-		c->q_parity ^= 1;
-	}
+	                                 d_steps, d_entry, stats, leap, c->stream));
 	return HMRM_OK;
 }
 
@@ -803,8 +745,6 @@ double hmrm_bench_kernel_ms(const hmrm_scene *scene, const hmrm_camera *cam, int
 		FrameSlot *slot = nullptr;
 		if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
 		hmrm::RowMap rows{0, cam->height, 0, 0, 1, 0};
-		// (one untimed frame first: the ray queue is allocated on first use)
-		if ((rc = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;
 		HIP_TRY(hipEventRecord(s->ev0, s->stream));
 		for (int i = 0; i < iters; ++i)
 			if ((rc = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;

@@ -72,19 +72,6 @@ struct RowMap {
 	int32_t tile_rot;      // launch order: grid row j renders tile row (j + tile_rot) mod tile rows (api.cpp)
 };
 
-// Rays the tile kernel (render_fast.hip) hands over to the ray-queue kernel (march_queue.hip)
-// after `pass1_trips` trips of its loop: position of the next untested step, pixel, remaining step
-// budget and pyramid level.  Structure of arrays, `capacity` entries each; *count is how many rays
-// asked for a slot this frame (the ones beyond capacity were not queued and finished in place).
-struct RayQueue {
-	double *x, *y, *z;
-	int32_t *px, *lrow;
-	int32_t *budget, *lev;
-	uint32_t *count;
-	uint32_t capacity;
-	int32_t pass1_trips;   // 0 = no hand-over (single pass)
-};
-
 // Host: fill everything except the table pointers / thr_max / step_cap.
 // Also fills the spherical tables (host arrays of screen_w / screen_h doubles) when
 // projection == 2.  Returns false on invalid arguments.

@@ -1,6 +1,6 @@
-// leap_common.hpp -- the exact-leap arithmetic shared by the tile kernel (render_fast.hip) and the
-// ray-queue kernel (march_queue.hip): cell coordinates, the saturating (int) cast and the per-axis
-// "same binade => p_k = p_0 + k*delta exactly" state.  The argument is in render_fast.hip's header;
+// leap_common.hpp -- the exact-leap arithmetic of the production kernel (render_fast.hip): cell
+// coordinates, the saturating (int) cast and the per-axis "same binade => p_k = p_0 + k*delta exactly"
+// state.  The argument is in render_fast.hip's header;
 // tests/test_leap_math.py checks the arithmetic model by brute force.  Include only from .hip files
 // compiled with -ffp-contract=off.
 #pragma once

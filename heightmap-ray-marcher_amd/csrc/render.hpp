@@ -25,18 +25,10 @@ hipError_t launch_render(const DevFrame &f, const RowMap &rows, const double *d_
 
 // Production kernel (render_fast.hip): speculative step groups, plus exact leaps over
 // empty pyramid blocks when `leap`.  Same outputs as launch_render.
-// `queue.pass1_trips > 0` (leap && nearest sampling only): rays still marching after that many loop
-// trips are appended to `queue` instead; launch_march_queue must follow on the same stream.
 hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr,
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
-                              bool leap, const RayQueue &queue, hipStream_t stream);
-// Second pass (march_queue.hip): finishes the queued rays, several lanes per ray, and zeroes
-// *d_next_count (the counter the NEXT frame's first pass appends through).
-hipError_t launch_march_queue(const DevFrame &f, const RowMap &rows, const double *d_thr,
-                              const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
-                              unsigned long long *d_counters, uint32_t *d_steps, bool stats,
-                              const RayQueue &queue, uint32_t *d_next_count, hipStream_t stream);
+                              bool leap, hipStream_t stream);
 // 3x3 maximum filter of the thr table (bounds every bilinear interpolation, render_fast.hip).
 hipError_t launch_dilate3x3(const double *d_thr, int w, int h, double *d_dst, hipStream_t stream);
 // Window-maximum pyramid (see render_fast.hip): level 0 from the thr table, level l+1 from level l.

@@ -109,16 +109,13 @@ __device__ __forceinline__ uint32_t shade_hit_bilinear(const DevFrame &f, const 
 #else
 #define HMRM_OCCUPANCY_ATTR
 #endif
-template <int PROJ, bool STATS, int GWM, bool LEAP, bool BILINEAR, bool QUEUE>
+template <int PROJ, bool STATS, int GWM, bool LEAP, bool BILINEAR>
 __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR void k_render_fast(const DevFrame f, const RowMap rows,
                                                      const double *__restrict__ thr,
                                                      const uint32_t *__restrict__ cmap,
                                                      uint32_t *__restrict__ out, int64_t out_stride_px,
-                                                     int tiles_y, StatsOut st, const RayQueue q) {
+                                                     int tiles_y, StatsOut st) {
 	const PixelId pid = pixel_of_lane(f, rows, tiles_y);
-#ifdef HMRM_EXP_SKIP_ROWS_BELOW
-	if (pid.py < HMRM_EXP_SKIP_ROWS_BELOW) return; // experiment only: what do the rows above cost in the mix?
-#endif
 	const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull; // tools-only timing
 	unsigned long long my_steps = 0;
 	uint32_t my_hit = 0, my_cap = 0;
@@ -136,7 +133,6 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 
 		uint32_t rgba = 0;
 		bool real_hit = false;
-		bool queued = false; // handed over to the ray-queue kernel, which then writes this pixel
 
 		if (!(d == __builtin_huge_val()) && !(d < 0.0)) { // intersection(), AABB.cpp:33-44
 			double x = ray.px + d * ray.dx;
@@ -181,15 +177,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 			// branch any of its lanes takes, and exec-mask juggling per `if` costs as much as
 			// the arithmetic it guards.  Values are computed for all lanes and selected.
 			bool done = entry_nan;
-			// Two-pass split (QUEUE): after `pass1_trips` trips a ray still marching is appended to the
-			// ray queue and finished by k_march_queue (march_queue.hip), which spends several lanes per ray
-			// and spreads the stragglers of one tile over the whole chip; its state is the position of
-			// the next untested step, the step budget and the level.  If the queue is full the ray just
-			// carries on here.
-			int trip = 0;
-			int trip_limit = (QUEUE && q.pass1_trips > 0) ? q.pass1_trips : 0x7fffffff;
-			for (;;) {
-			for (; !done && trip < trip_limit; ++trip) {
+			while (!done) {
 				bool skip_group = false;
 				bool dg_attempted = false; // diagnostics only
 				// ---------------------------------------------------------- leap
@@ -507,36 +495,13 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 				y = Y[kGroup - 1] + sy;
 				z = Z[kGroup - 1] + sz;
 			}
-			if (!QUEUE || done) break;
-			// hand-over: the lanes of the wave still marching arrive here together (same trip count);
-			// one atomic per wave reserves their slots
-			const unsigned long long arriving = __ballot(true);
-			const int lane = (int)(threadIdx.x & 63u);
-			const unsigned rank = (unsigned)__popcll(arriving & ((1ull << lane) - 1ull));
-			unsigned first_slot = 0;
-			if (rank == 0) first_slot = atomicAdd(q.count, (unsigned)__popcll(arriving));
-			first_slot = (unsigned)__builtin_amdgcn_readfirstlane((int)first_slot); // (the lowest arriving lane has rank 0)
-			const unsigned slot = first_slot + rank;
-			if (slot < q.capacity) {
-				q.x[slot] = x;
-				q.y[slot] = y;
-				q.z[slot] = z;
-				q.px[slot] = pid.px;
-				q.lrow[slot] = pid.lrow;
-				q.budget[slot] = budget;
-				q.lev[slot] = lev;
-				queued = true;
-				break;
-			}
-			trip_limit = 0x7fffffff; // queue full: finish here
-			}
-			if (STATS) my_steps = queued ? 0ull : (unsigned long long)(unsigned)(budget0 - budget);
+			if (STATS) my_steps = (unsigned long long)(unsigned)(budget0 - budget);
 		}
 
 		if (real_hit) my_hit = 1;
-		else if (!queued) rgba = shade_miss(f, ray.dz);
-		if (!queued) out[(int64_t)pid.lrow * out_stride_px + pid.px] = rgba;
-		if (STATS && st.steps_per_pixel && !queued)
+		else rgba = shade_miss(f, ray.dz);
+		out[(int64_t)pid.lrow * out_stride_px + pid.px] = rgba;
+		if (STATS && st.steps_per_pixel)
 			st.steps_per_pixel[(int64_t)pid.py * f.screen_w + pid.px] =
 			    f.diag_mode == 1 ? ((dg_attempts > 0xffffu ? 0xffffu : dg_attempts) << 16) |
 			                       (dg_groups > 0xffffu ? 0xffffu : dg_groups)
@@ -660,59 +625,56 @@ hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *
 template <int PROJ, bool STATS, int GWM, bool LEAP>
 static void launch_one(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
                        uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid, int tiles_y,
-                       const RayQueue &q, hipStream_t stream) {
+                       hipStream_t stream) {
 	if (f.sampling == 1)
-		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, true, false>), grid, dim3(kBlockThreads), 0, stream, f, rows,
-		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q);
-	else if (LEAP && q.pass1_trips > 0)
-		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, false, LEAP>), grid, dim3(kBlockThreads), 0, stream, f, rows,
-		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q);
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, true>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
 	else
-		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, false, false>), grid, dim3(kBlockThreads), 0, stream, f, rows,
-		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q);
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, false>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
 }
 
 template <int PROJ, bool STATS, int GWM>
 static void launch_leap(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
-                        int tiles_y, const RayQueue &q, hipStream_t stream) {
-	if (leap) launch_one<PROJ, STATS, GWM, true>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream);
-	else launch_one<PROJ, STATS, GWM, false>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream);
+                        int tiles_y, hipStream_t stream) {
+	if (leap) launch_one<PROJ, STATS, GWM, true>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	else launch_one<PROJ, STATS, GWM, false>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 }
 
 template <int PROJ, bool STATS>
 static void launch_gwm(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                        const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
-                       int tiles_y, const RayQueue &q, hipStream_t stream) {
+                       int tiles_y, hipStream_t stream) {
 	switch (f.grid_mode) {
-	case 0: launch_leap<PROJ, STATS, 0>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
-	case 1: launch_leap<PROJ, STATS, 1>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
-	default: launch_leap<PROJ, STATS, 2>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
+	case 0: launch_leap<PROJ, STATS, 0>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	case 1: launch_leap<PROJ, STATS, 1>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	default: launch_leap<PROJ, STATS, 2>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
 	}
 }
 
 template <bool STATS>
 static void launch_proj(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
-                        int tiles_y, const RayQueue &q, hipStream_t stream) {
+                        int tiles_y, hipStream_t stream) {
 	switch (f.projection) {
-	case 1: launch_gwm<1, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
-	case 2: launch_gwm<2, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
-	default: launch_gwm<3, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream); break;
+	case 1: launch_gwm<1, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	case 2: launch_gwm<2, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
+	default: launch_gwm<3, STATS>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream); break;
 	}
 }
 
 hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr,
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
-                              bool leap, const RayQueue &q, hipStream_t stream) {
+                              bool leap, hipStream_t stream) {
 	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
 	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
 	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
 	const dim3 grid((unsigned)tiles_x, (unsigned)(tiles_y < 32768 ? tiles_y : 32768), (unsigned)((tiles_y + 32767) / 32768));
 	StatsOut st{d_counters, d_steps, d_entry};
-	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream);
-	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, q, stream);
+	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 	return hipGetLastError();
 }
 

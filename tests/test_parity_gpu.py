@@ -460,93 +460,6 @@ def test_random_cameras_and_parameters_fuzz(gpu, oracle):
     assert checked == 48 and leaped > 0
 
 
-@pytest.mark.parametrize("trips", [1, 2, 5])
-def test_two_pass_hand_over_edge_scenes(gpu, oracle, trips):
-    """Two-pass march (render_fast.hip -> march_queue.hip): rays handed to the ray-queue kernel after
-    `trips` loop trips (HMRM_PASS1_TRIPS; the default hands over only stragglers) must end exactly as
-    in the reference: frame, per-ray step counts, totals -- on every edge-case scene."""
-    with env(HMRM_PASS1_TRIPS=trips, HMRM_STEP_CAP=300000):
-        for case in scenes.cases():
-            name, rgb, cmap, params, cam = scenes.build_case(case)
-            scene = gpu.Scene(rgb, cmap, params)
-            heights = oracle.update_heightmap(rgb, params)
-            cfg = oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0], step_cap=300000)
-            ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True)
-            fb, st, steps, entry = scene.render_stats(cam, per_pixel=True, allow_capped=True)
-            assert np.array_equal(fb, ofb), (name, trips)
-            ok = osteps >= 0  # (the oracle marks a capped ray with -(cap + 1))
-            assert np.array_equal(steps.astype(np.int64)[ok], osteps[ok]), (name, trips)
-            assert (st.steps, st.capped) == (total, capped), (name, trips)
-            if capped == 0:
-                assert np.array_equal(scene.render(cam), ofb), (name, trips)
-            scene.close()
-
-
-def test_two_pass_fuzz_and_step_cap(gpu, oracle):
-    """Seeded fuzz with everything handed over after one trip, including rays that reach a small step
-    cap inside the ray-queue kernel (cap reported, steps == cap)."""
-    rng = np.random.RandomState(77)
-    handed = 0
-    for trial in range(40):
-        cap = int(rng.choice([300000, 5000, 700]))
-        with env(HMRM_PASS1_TRIPS=int(rng.choice([1, 1, 3])), HMRM_STEP_CAP=cap):
-            mw, mh = int(rng.choice([48, 96, 257, 600])), int(rng.choice([48, 131, 300]))
-            rgb, cmap = scenes.small_maps(mw, mh, 5000 + trial, color_heights=bool(trial % 2))
-            gw = float(rng.choice([1.0, 0.5, 0.05, 0.3, 1.7]))
-            lo = float(rng.choice([0.0, -1.5, 2.0]))
-            hi = lo + float(rng.uniform(0.5, 0.2 * mw)) * gw
-            params = gpu.SceneParams.make(lo, hi, grid_width=gw)
-            ext_x, ext_y = mw * gw, mh * gw
-            ang = rng.uniform(0, 2 * np.pi)
-            dist = rng.uniform(0.55, 1.4) * max(ext_x, ext_y)
-            pos = (ext_x / 2 + dist * np.cos(ang), -ext_y / 2 + dist * np.sin(ang), hi + rng.uniform(0.0, 1.0) * (hi - lo + gw))
-            cam = gpu.Camera.make(width=int(rng.randint(17, 120)), height=int(rng.randint(9, 90)),
-                                  projection=int(rng.choice([1, 2, 3])),
-                                  hfov=float(gpu.degrees_to_rads(rng.uniform(30, 175))),
-                                  hang=float(np.arctan2(-ext_y / 2 - pos[1], ext_x / 2 - pos[0]) + rng.uniform(-0.3, 0.3)),
-                                  vang=float(gpu.degrees_to_rads(rng.uniform(80, 150))), pos=pos,
-                                  ortho_width=float(rng.uniform(0.2, 3.0) * gw),
-                                  step_dist=float(rng.choice([0.05, 0.1, 0.25, 0.5, 0.37]) * gw),
-                                  bg=tuple(int(v) for v in rng.randint(0, 256, size=3)))
-            heights = oracle.update_heightmap(rgb, params)
-            ofb, total, capped, osteps, _ = oracle.render(oracle.make_cfg(cam, params, mw, mh, step_cap=cap), heights,
-                                                          cmap, per_pixel=True)
-            scene = gpu.Scene(rgb, cmap, params)
-            fb, st, steps, _ = scene.render_stats(cam, per_pixel=True, allow_capped=True)
-            label = (trial, cam.projection, gw, cam.step_dist, cap)
-            assert np.array_equal(fb, ofb), label
-            ok = osteps >= 0  # (the oracle marks a capped ray with -(cap + 1))
-            assert np.array_equal(steps.astype(np.int64)[ok], osteps[ok]) and (steps[~ok] == cap).all(), label
-            assert st.steps == total and st.capped == capped == int((~ok).sum()), label
-            handed += int(st.steps > 0)
-            scene.close()
-    assert handed > 20
-
-
-@pytest.mark.parametrize("wl_name,trips", [("C3", 2), ("C5", 3), ("C3", 24)])
-def test_two_pass_full_size_equals_single_pass(gpu, oracle, wl_name, trips):
-    """BASELINE sizes: the two-pass frame and per-ray step counts equal the single-pass kernel's
-    (HMRM_PASS1_TRIPS=0) and, on every 48th row, the oracle's."""
-    wl = gpu.synth.WORKLOADS[wl_name]
-    rgb, cmap = gpu.synth.synth_maps(wl.map_size)
-    params, cam = wl.scene_params(), wl.camera()
-    scene = gpu.Scene(rgb, cmap, params)
-    with env(HMRM_PASS1_TRIPS=0):
-        fb1, st1, steps1, _ = scene.render_stats(cam, per_pixel=True)
-    with env(HMRM_PASS1_TRIPS=trips):
-        fb2, st2, steps2, _ = scene.render_stats(cam, per_pixel=True)
-        plain = scene.render(cam)
-    assert np.array_equal(fb2, fb1) and np.array_equal(plain, fb1)
-    assert np.array_equal(steps2, steps1) and (st2.steps, st2.hits, st2.capped) == (st1.steps, st1.hits, 0)
-    heights = oracle.update_heightmap(rgb, params)
-    stride = 48
-    ofb, _, capped, osteps, _ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap,
-                                              per_pixel=True, row_stride=stride)
-    rows = slice(0, cam.height, stride)
-    assert capped == 0 and np.array_equal(fb2[rows], ofb[rows]) and np.array_equal(steps2[rows].astype(np.int64), osteps[rows])
-    scene.close()
-
-
 def test_progressive_cycle_refresh(gpu, oracle):
     """`cycle n` (hmap.cpp:976-983): each call rewrites pixels p = cycle (mod n); n calls give the frame."""
     rgb, cmap = scenes.small_maps(64, 64, 55)

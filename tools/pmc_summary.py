@@ -4,9 +4,8 @@
 usage: pmc_summary.py <gpurun_out/prof_dir> <workload> <out_prefix>
 
 Reads every */*_counter_collection.csv, *_kernel_trace.csv and *_kernel_stats.csv below the directory.
-A frame is one launch of each render kernel of the product (k_render_fast, and k_march_queue when the
-two-pass split is on); counters are averaged per dispatch and kernel, then summed over the kernels of a
-frame.  The instrumented instantiations (STATS = true) are left out.
+A frame is one launch of the product's render kernel (k_render_fast); counters are averaged per dispatch
+and kernel (and summed over kernels, should a frame ever take more than one).  The instrumented instantiations (STATS = true) are left out.
 
 Units and corrections (MI355X_MICROARCH.md, HBM / rocprofv3 sections, and tools/valu_calib.hip):
   * FETCH_SIZE / WRITE_SIZE are in KiB.  FETCH_SIZE counts 64 B per request and reads half the bytes of
@@ -31,7 +30,7 @@ CYC_F64, CYC_TRANS64, CYC_OTHER = 4.0, 16.0, 2.3
 
 
 def product_kernel(name):
-    if "k_render_fast<" in name or "k_march_queue<" in name or "k_render<" in name:
+    if "k_render_fast<" in name or "k_render<" in name:
         args = name.split("<", 1)[1]
         fields = [a.strip() for a in args.split(">")[0].split(",")]
         return len(fields) < 2 or fields[1] != "true"  # STATS is the second template argument
