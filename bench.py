@@ -184,7 +184,7 @@ def main():
             parallelism = "1 GPU"
         else:
             # BASELINE config C5's sharding: frame k of the 64-frame orbit on GPU k mod world
-            mine = [k % ORBIT_FRAMES for k in range(rank, rank + world * (args.warmup + args.steps), world)]
+            mine = strips.orbit_frames_of_rank(rank, world, args.warmup + args.steps, ORBIT_FRAMES)
             cams = {k: wl.camera(k, ORBIT_FRAMES) for k in sorted(set(mine))}
             steps_of = {k: int(scene.render_stats(c)[1].steps) for k, c in cams.items()}  # untimed, instrumented
             orbit = {"it": iter(mine), "last": None}

@@ -108,6 +108,20 @@ struct StreamCtx {
 	unsigned long long capped_seen = 0; // value of [2] the host has already reported
 };
 
+// One slot of the asynchronous read-back ring (hmrm_render_begin/_wait/_release): a device frame
+// the kernel writes, a pinned host frame the copy engine fills while the next kernel runs, and the
+// events that order the two streams.
+struct RingFrame {
+	uint32_t *d_frame = nullptr;
+	uint8_t *h_frame = nullptr; // pinned
+	unsigned long long *h_capped = nullptr; // pinned: the stream's cumulative capped-ray counter after this frame
+	size_t px = 0;
+	int32_t width = 0, height = 0;
+	hipEvent_t kernel_done = nullptr, copy_done = nullptr;
+	bool busy = false;
+};
+constexpr int kMaxRing = 64;
+
 struct hmrm_scene {
 	int device = 0;
 	int32_t map_w = 0, map_h = 0;
@@ -123,6 +137,8 @@ struct hmrm_scene {
 	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/16/64/256-cell windows every 2/8/32/128 cells
 	int32_t mip_w[hmrm::kMipLevels] = {}, mip_h[hmrm::kMipLevels] = {}, mip_off[hmrm::kMipLevels] = {};
 	hipStream_t stream = nullptr; // the scene's own stream (hmrm_render, updates)
+	hipStream_t copy_stream = nullptr; // device-to-host copies of the asynchronous ring
+	std::vector<RingFrame *> ring;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	unsigned long long *d_maxkey = nullptr; // UpdateHeightmap's max(thr) reduction
 	// scratch of the host-memory entry points (hmrm_render*, one caller at a time)
@@ -487,6 +503,7 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 	auto body = [&]() -> int {
 		HIP_TRY(hipGetDevice(&s->device));
 		HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
 		HIP_TRY(hipEventCreate(&s->ev0));
 		HIP_TRY(hipEventCreate(&s->ev1));
 		HIP_TRY(hipMalloc((void **)&s->d_rgb, n * 3));
@@ -540,6 +557,17 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 		destroy_ctx(c);
 	}
 	s->ctxs.clear();
+	if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+	for (RingFrame *r : s->ring) {
+		if (r->d_frame) (void)hipFree(r->d_frame);
+		if (r->h_frame) (void)hipHostFree(r->h_frame);
+		if (r->h_capped) (void)hipHostFree(r->h_capped);
+		if (r->kernel_done) (void)hipEventDestroy(r->kernel_done);
+		if (r->copy_done) (void)hipEventDestroy(r->copy_done);
+		delete r;
+	}
+	s->ring.clear();
+	if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
 	if (s->d_rgb) (void)hipFree(s->d_rgb);
 	if (s->d_cmap) (void)hipFree(s->d_cmap);
 	if (s->d_thr) (void)hipFree(s->d_thr);
@@ -725,6 +753,105 @@ int hmrm_scene_take_capped(const hmrm_scene *scene, void *hip_stream, uint64_t *
 	return HMRM_OK; // nothing was ever launched on that stream
 }
 
+// ---- asynchronous frames: kernel k+1 runs while frame k crosses PCIe (the reference's counterpart is
+// the blit of the finished framebuffer, SDL_UpdateTexture, hmap.cpp:1082) ----
+int hmrm_render_begin(const hmrm_scene *scene, const hmrm_camera *cam, int32_t *ticket) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
+	int rc = check_camera(cam);
+	if (rc) return rc;
+	if (!s || !ticket) return fail(HMRM_E_ARG, "NULL argument");
+	*ticket = -1;
+	const size_t W = (size_t)cam->width, H = (size_t)cam->height;
+	HIP_TRY(hipSetDevice(s->device));
+	std::lock_guard<std::mutex> lk(s->mu);
+	int idx = -1;
+	for (size_t i = 0; i < s->ring.size(); ++i)
+		if (!s->ring[i]->busy) {
+			idx = (int)i;
+			break;
+		}
+	if (idx < 0) {
+		if ((int)s->ring.size() >= kMaxRing) return fail(HMRM_E_ARG, "hmrm_render_begin: every frame of the ring is in use (release one)");
+		RingFrame *r = new (std::nothrow) RingFrame();
+		if (!r) return fail(HMRM_E_ARG, "out of memory");
+		s->ring.push_back(r);
+		idx = (int)s->ring.size() - 1;
+		HIP_TRY(hipEventCreateWithFlags(&r->kernel_done, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&r->copy_done, hipEventDisableTiming));
+		HIP_TRY(hipHostMalloc((void **)&r->h_capped, sizeof(unsigned long long), hipHostMallocDefault));
+	}
+	RingFrame *r = s->ring[(size_t)idx];
+	if (W * H > r->px) {
+		// (the slot is free: nothing in flight touches its buffers)
+		if (r->d_frame) (void)hipFree(r->d_frame);
+		if (r->h_frame) (void)hipHostFree(r->h_frame);
+		r->d_frame = nullptr;
+		r->h_frame = nullptr;
+		r->px = 0;
+		HIP_TRY(hipMalloc((void **)&r->d_frame, W * H * sizeof(uint32_t)));
+		HIP_TRY(hipHostMalloc((void **)&r->h_frame, W * H * 4, hipHostMallocDefault));
+		r->px = W * H;
+	}
+	StreamCtx *c = nullptr;
+	if ((rc = ctx_for(s, s->stream, &c))) return rc;
+	hmrm::DevFrame f;
+	FrameSlot *slot = nullptr;
+	if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
+	hmrm::RowMap rows{0, cam->height, 0, 0, 1, 0};
+	if ((rc = launch_frame(s, c, f, slot, rows, r->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;
+	HIP_TRY(hipEventRecord(r->kernel_done, s->stream));
+	HIP_TRY(hipStreamWaitEvent(s->copy_stream, r->kernel_done, 0));
+	HIP_TRY(hipMemcpyAsync(r->h_frame, r->d_frame, W * H * 4, hipMemcpyDeviceToHost, s->copy_stream));
+	HIP_TRY(hipMemcpyAsync(r->h_capped, c->d_counters + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+	                       s->copy_stream));
+	HIP_TRY(hipEventRecord(r->copy_done, s->copy_stream));
+	r->width = cam->width;
+	r->height = cam->height;
+	r->busy = true;
+	*ticket = idx;
+	return HMRM_OK;
+}
+
+int hmrm_render_wait(const hmrm_scene *scene, int32_t ticket, const uint8_t **rgba, size_t *stride_bytes) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
+	if (!s || !rgba) return fail(HMRM_E_ARG, "NULL argument");
+	RingFrame *r = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(s->mu);
+		if (ticket < 0 || ticket >= (int)s->ring.size() || !s->ring[(size_t)ticket]->busy)
+			return fail(HMRM_E_ARG, "hmrm_render_wait: no such frame in flight");
+		r = s->ring[(size_t)ticket];
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipEventSynchronize(r->copy_done)); // (outside the lock: other threads may begin frames meanwhile)
+	*rgba = r->h_frame;
+	if (stride_bytes) *stride_bytes = (size_t)r->width * 4;
+	std::lock_guard<std::mutex> lk(s->mu);
+	StreamCtx *c = nullptr;
+	const int rc = ctx_for(s, s->stream, &c);
+	if (rc) return rc;
+	// the counter is cumulative over the stream's launches: later frames may already be in it, so a
+	// capped ray is reported with the first frame waited for after it happened
+	if (*r->h_capped > c->capped_seen) {
+		const unsigned long long n = *r->h_capped - c->capped_seen;
+		c->capped_seen = *r->h_capped;
+		return noterm(n);
+	}
+	return HMRM_OK;
+}
+
+void hmrm_render_release(const hmrm_scene *scene, int32_t ticket) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
+	if (!s) return;
+	std::lock_guard<std::mutex> lk(s->mu);
+	if (ticket < 0 || ticket >= (int)s->ring.size()) return;
+	RingFrame *r = s->ring[(size_t)ticket];
+	if (!r->busy) return;
+	(void)hipSetDevice(s->device);
+	(void)hipEventSynchronize(r->copy_done); // never hand a slot back while the copy engine writes it
+	r->busy = false;
+}
+
 double hmrm_last_kernel_ms(void) { return g_last_kernel_ms; }
 
 double hmrm_bench_kernel_ms(const hmrm_scene *scene, const hmrm_camera *cam, int32_t iters) {
@@ -833,6 +960,7 @@ const char *hmrm_config_heightmap_path(const hmrm_config *c) { return c->cfg.hei
 const char *hmrm_config_colormap_path(const hmrm_config *c) { return c->cfg.colormap_path.c_str(); }
 const char *hmrm_config_output_path(const hmrm_config *c) { return c->cfg.output_path.c_str(); }
 int32_t hmrm_config_record_mode(const hmrm_config *c) { return c->cfg.record_mode; }
+int32_t hmrm_config_devices(const hmrm_config *c) { return c->cfg.devices; }
 
 const uint8_t *hmrm_config_height_rgb(const hmrm_config *c, int32_t *w, int32_t *h) {
 	if (!c->cfg.have_heightmap) return nullptr;

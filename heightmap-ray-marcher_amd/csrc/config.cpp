@@ -197,6 +197,10 @@ bool Config::consume(std::istream &input, std::string *fatal) {
 			else if (v == "bilinear") sampling = 1;
 			else warn << "WARNING: Unknown sampling: " << v << "\n";
 			log << "sampling " << (sampling == 1 ? "bilinear" : "nearest") << "\n";
+		} else if (next == "devices") { // additive: multi-GPU recording (BASELINE config C5)
+			input >> devices;
+			if (devices < 0) devices = 1;
+			log << "devices " << devices << "\n";
 		} else if (next == "record") { // additive: programmatic animation (hmap.cpp:907-926 is a stub)
 			std::string v;
 			input >> v;

@@ -34,6 +34,8 @@ struct Config {
 	std::string output_path;
 	// additive: `record orbit` renders recording_frame_count frames of an orbit sweep
 	int record_mode = 0;
+	// additive: `devices n` -- GPUs the recording is sharded over, frame k on device k mod n (0 = all visible)
+	int devices = 1;
 	// additive: `sampling nearest|bilinear` (nearest = the reference's truncating lookup)
 	int sampling = 0;
 

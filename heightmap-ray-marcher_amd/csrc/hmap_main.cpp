@@ -42,6 +42,11 @@ int main(int argc, char *argv[]) {
 
 	hmrm_camera cam;
 	hmrm_config_get_camera(cfg, &cam);
+	// (the library applies the same test, check_camera; here it guards the framebuffer allocation below)
+	if (cam.width <= 0 || cam.height <= 0 || (long long)cam.width * cam.height > (1LL << 31) / 4) {
+		std::cerr << "resolution must be positive and at most 2^29 pixels (the reference indexes the framebuffer with int)\n";
+		return 1;
+	}
 	hmrm_scene *scene = NULL;
 	if (hmrm_config_create_scene(cfg, &scene) != HMRM_OK) {
 		std::cerr << hmrm_last_error() << "\n";
@@ -68,9 +73,23 @@ int main(int argc, char *argv[]) {
 		std::string dir = hmrm_config_output_path(cfg);
 		if (dir.empty()) dir = "screenshots";
 		mkdir(dir.c_str(), 0777);
-		rc = hmrm_record_orbit(scene, &cam, cx, cy, radius, hang0, hmrm_config_recording_frame_count(cfg),
-		                       dir.c_str(), (long long)id, 0, 1);
+		// `devices n`: one scene per GPU, frame k on device k mod n (BASELINE config C5); the scene
+		// created above lives on device 0
+		int ndev = hmrm_config_devices(cfg);
+		const int visible = hmrm_device_count();
+		if (ndev <= 0 || ndev > visible) ndev = visible > 0 ? visible : 1;
+		std::vector<hmrm_scene *> scenes(1, scene);
+		for (int d = 1; d < ndev && rc == HMRM_OK; ++d) {
+			hmrm_scene *extra = NULL;
+			rc = hmrm_set_device(d);
+			if (rc == HMRM_OK) rc = hmrm_config_create_scene(cfg, &extra);
+			if (rc == HMRM_OK) scenes.push_back(extra);
+		}
+		if (rc == HMRM_OK)
+			rc = hmrm_record_orbit_multi(scenes.data(), (int32_t)scenes.size(), &cam, cx, cy, radius, hang0,
+			                             hmrm_config_recording_frame_count(cfg), dir.c_str(), (long long)id, 0, 1);
 		if (rc != HMRM_OK) std::cerr << hmrm_last_error() << "\n";
+		for (size_t i = 1; i < scenes.size(); ++i) hmrm_scene_destroy(scenes[i]);
 		hmrm_scene_destroy(scene);
 		hmrm_config_destroy(cfg);
 		return rc == HMRM_OK ? 0 : 1;

@@ -115,6 +115,13 @@ def _load():
         "hmrm_record_orbit": (C.c_int, [vp, C.POINTER(Camera), C.c_double, C.c_double, C.c_double, C.c_double, i32,
                                         C.c_char_p, C.c_longlong, i32, i32]),
         "hmrm_config_record_mode": (i32, [vp]),
+        "hmrm_config_devices": (i32, [vp]),
+        "hmrm_record_orbit_multi": (C.c_int, [C.POINTER(vp), i32, C.POINTER(Camera), C.c_double, C.c_double, C.c_double,
+                                              C.c_double, i32, C.c_char_p, C.c_longlong, i32, i32]),
+        "hmrm_orbit_frame_owner": (i32, [i32, i32]),
+        "hmrm_render_begin": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(i32)]),
+        "hmrm_render_wait": (C.c_int, [vp, i32, C.POINTER(u8p), C.POINTER(C.c_size_t)]),
+        "hmrm_render_release": (None, [vp, i32]),
         "hmrm_config_create": (vp, []),
         "hmrm_config_destroy": (None, [vp]),
         "hmrm_config_consume_file": (C.c_int, [vp, C.c_char_p]),
@@ -278,6 +285,28 @@ class Scene:
                                            row_begin, row_end, band_rows, band_index, band_count,
                                            C.c_void_p(stream)))
 
+    def render_begin(self, cam: Camera) -> int:
+        """Enqueue a frame (kernel + copy into a pinned frame of the scene's ring) -> ticket."""
+        self._sync_env()
+        t = C.c_int32()
+        _check(lib.hmrm_render_begin(self._h, C.byref(cam), C.byref(t)))
+        return int(t.value)
+
+    def render_wait(self, ticket: int, shape, allow_capped=False, copy=True) -> np.ndarray:
+        """Wait for the frame of `ticket` -> HxWx4 uint8 (a copy, or with copy=False a view of the
+        ring's pinned memory that is valid until render_release)."""
+        p = C.POINTER(C.c_uint8)()
+        stride = C.c_size_t()
+        _check(lib.hmrm_render_wait(self._h, ticket, C.byref(p), C.byref(stride)),
+               allow=(HMRM_E_NOTERM,) if allow_capped else ())
+        h, w = shape
+        assert stride.value == w * 4
+        a = np.ctypeslib.as_array(p, shape=(h, w, 4))
+        return a.copy() if copy else a
+
+    def render_release(self, ticket: int):
+        lib.hmrm_render_release(self._h, ticket)
+
     def take_capped(self, stream: int = 0, allow_capped=False) -> int:
         """Rays of the launches enqueued on `stream` that reached the step cap since the last call
         (waits for the stream); raises HMRM_E_NOTERM for a non-zero count unless allowed."""
@@ -327,6 +356,19 @@ def record_orbit(scene: "Scene", base: Camera, centre_x, centre_y, radius, hang0
     _check(lib.hmrm_record_orbit(scene._h, C.byref(base), centre_x, centre_y, radius, hang0, frames,
                                  os.fsencode(directory), rec_id, encoder_threads, int(verbose)),
            allow=(HMRM_E_NOTERM,))
+
+
+def record_orbit_multi(scenes, base: Camera, centre_x, centre_y, radius, hang0, frames, directory, rec_id,
+                       encoder_threads=0, verbose=False):
+    """The sweep sharded over several scenes (one per GPU): frame k on scenes[k mod len(scenes)]."""
+    arr = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    _check(lib.hmrm_record_orbit_multi(arr, len(scenes), C.byref(base), centre_x, centre_y, radius, hang0, frames,
+                                       os.fsencode(directory), rec_id, encoder_threads, int(verbose)),
+           allow=(HMRM_E_NOTERM,))
+
+
+def orbit_frame_owner(frame: int, n_devices: int) -> int:
+    return int(lib.hmrm_orbit_frame_owner(frame, n_devices))
 
 
 def band_local_rows(height, band_rows, band_index, band_count) -> int:
@@ -391,6 +433,10 @@ class Config:
     @property
     def record_mode(self) -> int:
         return lib.hmrm_config_record_mode(self._h)
+
+    @property
+    def devices(self) -> int:
+        return lib.hmrm_config_devices(self._h)
 
     @property
     def output_path(self) -> str:

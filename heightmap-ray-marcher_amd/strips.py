@@ -48,6 +48,14 @@ class BandPlan:
         return rows
 
 
+def orbit_frames_of_rank(rank: int, world: int, count: int, orbit_frames: int = 64):
+    """Frame sharding of a recording (BASELINE config C5): frame k of the orbit belongs to GPU
+    k mod world.  -> the first `count` frames rank `rank` renders, in order: rank, rank + world, ...
+    (wrapping around the orbit after `orbit_frames`, so that a bench can time more frames than the
+    orbit has).  The C ABI's hmrm_orbit_frame_owner is the same rule seen from the frame."""
+    return [k % orbit_frames for k in range(rank, rank + world * count, world)]
+
+
 def reassemble_numpy(plan: BandPlan, strips) -> np.ndarray:
     """strips[rank] = (strip_rows, width, 4) uint8 -> (height, width, 4)."""
     out = np.zeros((plan.height, plan.width, 4), dtype=np.uint8)

@@ -130,6 +130,17 @@ int  hmrm_scene_read_heights(const hmrm_scene *scene, double *out);
 int hmrm_render(const hmrm_scene *scene, const hmrm_camera *cam,
                 uint8_t *rgba, size_t stride_bytes);
 
+/* The same frame without blocking: hmrm_render_begin enqueues the kernel and the device-to-host
+ * copy into a pinned frame owned by the scene and returns a ticket; hmrm_render_wait blocks until
+ * that frame is in host memory and lends it out (*rgba, valid until hmrm_render_release; returns
+ * HMRM_E_NOTERM like hmrm_render, the frame is still valid then).  Copies run on their own
+ * stream, so with two or more frames in flight kernel k+1 overlaps the PCIe transfer of frame k
+ * (replaces the per-frame blit SDL_UpdateTexture, hmap.cpp:1082).  Up to 64 frames in flight per
+ * scene; the ring grows on demand and is freed with the scene. */
+int  hmrm_render_begin(const hmrm_scene *scene, const hmrm_camera *cam, int32_t *ticket);
+int  hmrm_render_wait(const hmrm_scene *scene, int32_t ticket, const uint8_t **rgba, size_t *stride_bytes);
+void hmrm_render_release(const hmrm_scene *scene, int32_t ticket);
+
 /* The reference's progressive frame driver (hmap.cpp:976-983, `cycle n` key, default 47):
  * rewrites only pixels p = cycle, cycle + cycle_period, ... (p = x + y*width) of `rgba`
  * and leaves the others as they are; cycle_period consecutive calls with cycle = 0 ..
@@ -211,6 +222,14 @@ void hmrm_orbit_camera(const hmrm_camera *base, double centre_x, double centre_y
 int hmrm_record_orbit(const hmrm_scene *scene, const hmrm_camera *base, double centre_x, double centre_y,
                       double radius, double hang0, int32_t frames, const char *dir, long long id,
                       int32_t encoder_threads, int32_t verbose);
+/* The same sweep sharded over several scenes -- one per GPU, each created after hmrm_set_device
+ * with the same maps (BASELINE config C5): frame k is rendered by scenes[k mod n_scenes]
+ * (hmrm_orbit_frame_owner), no exchange between devices, one shared pool of encoder threads.
+ * Files and bytes are those of hmrm_record_orbit. */
+int hmrm_record_orbit_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_camera *base,
+                            double centre_x, double centre_y, double radius, double hang0, int32_t frames,
+                            const char *dir, long long id, int32_t encoder_threads, int32_t verbose);
+int32_t hmrm_orbit_frame_owner(int32_t frame, int32_t n_devices);
 
 /* ------------------------------------------------------------------- config */
 /* Replaces ConsumeConfigStream (main/hmap.cpp:309-520) and the globals'
@@ -218,7 +237,7 @@ int hmrm_record_orbit(const hmrm_scene *scene, const hmrm_camera *base, double c
  * every option to `echo_fd`-style sinks: echo text is appended to an internal
  * log retrievable with hmrm_config_log().  Additive keys (not in the reference,
  * named by north_star): `projection perspective|spherical|orthographic|1|2|3`,
- * `output <path.png|.ppm>`, `record orbit|off`, `sampling nearest|bilinear`.  Unknown key -> "WARNING: Unknown identifier: k". */
+ * `output <path.png|.ppm>`, `record orbit|off`, `devices n`, `sampling nearest|bilinear`.  Unknown key -> "WARNING: Unknown identifier: k". */
 hmrm_config *hmrm_config_create(void);
 void         hmrm_config_destroy(hmrm_config *cfg);
 /* Consume a whole stream; loads heightmap/colormap images when those keys
@@ -235,6 +254,7 @@ const char  *hmrm_config_heightmap_path(const hmrm_config *cfg);
 const char  *hmrm_config_colormap_path(const hmrm_config *cfg);
 const char  *hmrm_config_output_path(const hmrm_config *cfg);
 int32_t      hmrm_config_record_mode(const hmrm_config *cfg);   /* additive `record orbit|off`: 1|0 */
+int32_t      hmrm_config_devices(const hmrm_config *cfg);       /* additive `devices n`: GPUs for recording, 0 = all */
 /* Loaded maps (owned by cfg): RGB8 / RGBA8; NULL until the key was consumed. */
 const uint8_t *hmrm_config_height_rgb(const hmrm_config *cfg, int32_t *w, int32_t *h);
 const uint8_t *hmrm_config_color_rgba(const hmrm_config *cfg, int32_t *w, int32_t *h);

@@ -153,6 +153,11 @@ def test_record_key_and_orbit_camera(hmrm, maps):
     cfg = hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} record orbit recording_frame_count 64")
     assert cfg.record_mode == 1 and cfg.recording_frame_count == 64 and "record orbit" in cfg.log
     assert hmrm.Config().consume_string(f"heightmap {hp} colormap {cp}").record_mode == 0
+    # additive `devices n`: GPUs the recording is sharded over (frame k on device k mod n); default 1, 0 = all
+    assert hmrm.Config().consume_string(f"heightmap {hp} colormap {cp}").devices == 1
+    cfg8 = hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} devices 8 record orbit")
+    assert cfg8.devices == 8 and "devices 8" in cfg8.log
+    assert hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} devices 0").devices == 0
     wl = hmrm.synth.WORKLOADS["C5"]
     s = float(wl.map_size)
     static = wl.camera()

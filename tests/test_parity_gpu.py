@@ -460,6 +460,135 @@ def test_random_cameras_and_parameters_fuzz(gpu, oracle):
     assert checked == 48 and leaped > 0
 
 
+def test_async_ring_frames_in_flight(gpu, oracle):
+    """hmrm_render_begin/_wait/_release: several frames in flight (kernel k+1 beside the copy of frame
+    k), each equal to the oracle's frame for its camera, slots reusable after release."""
+    rgb, cmap = scenes.small_maps(96, 96, 21)
+    params = gpu.SceneParams.make(0.0, 9.0, grid_width=1.0)
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    base = gpu.Camera.make(width=160, height=90, projection=2, hfov=gpu.degrees_to_rads(150), hang=0.0,
+                           vang=gpu.degrees_to_rads(112), pos=(-30.0, 30.0, 40.0), step_dist=0.25, bg=(4, 5, 6))
+    cams = [gpu.orbit_camera(base, 48.0, -48.0, 90.0, gpu.degrees_to_rads(-45.0), k, 7) for k in range(7)]
+    want = [oracle.render(oracle.make_cfg(c, params, 96, 96), heights, cmap)[0] for c in cams]
+    for lap in range(2):
+        tickets = [scene.render_begin(c) for c in cams[:4]]           # four in flight
+        assert len(set(tickets)) == 4
+        for k in (0, 1):
+            assert np.array_equal(scene.render_wait(tickets[k], (90, 160)), want[k])
+            scene.render_release(tickets[k])
+        tickets += [scene.render_begin(c) for c in cams[4:]]           # reuses the released slots
+        for k in range(2, 7):
+            view = scene.render_wait(tickets[k], (90, 160), copy=False)
+            assert np.array_equal(view, want[k])
+            scene.render_release(tickets[k])
+    with pytest.raises(gpu.HmrmError):
+        scene.render_wait(tickets[0], (90, 160))                       # released: no such frame in flight
+    scene.close()
+
+
+def test_recording_sharded_over_scenes(gpu, oracle, tmp_path):
+    """hmrm_record_orbit_multi (BASELINE config C5: frame k on GPU k mod N): with one scene per
+    "device" (here two or three scenes on the one GPU of the box) the files are byte for byte those of
+    the single-scene recording and the oracle's frames."""
+    rgb, cmap = scenes.small_maps(64, 64, 43)
+    params = gpu.SceneParams.make(0.0, 8.0, grid_width=1.0)
+    base = gpu.Camera.make(width=96, height=54, projection=1, hfov=gpu.degrees_to_rads(80), hang=0.0,
+                           vang=gpu.degrees_to_rads(112), pos=(-20.0, 20.0, 30.0), step_dist=0.5, bg=(4, 5, 6))
+    heights = oracle.update_heightmap(rgb, params)
+    frames, cx, cy, radius, hang0 = 11, 32.0, -32.0, 70.0, gpu.degrees_to_rads(-45.0)
+    one = gpu.Scene(rgb, cmap, params)
+    d1 = tmp_path / "one"
+    d1.mkdir()
+    gpu.record_orbit(one, base, cx, cy, radius, hang0, frames, str(d1), 7, encoder_threads=2)
+    for n_scenes, threads in ((2, 3), (3, 1)):
+        many = [gpu.Scene(rgb, cmap, params) for _ in range(n_scenes)]
+        dn = tmp_path / f"many{n_scenes}"
+        dn.mkdir()
+        gpu.record_orbit_multi(many, base, cx, cy, radius, hang0, frames, str(dn), 7, encoder_threads=threads)
+        assert sorted(p.name for p in dn.iterdir()) == sorted(f"hmap_7_{k}.png" for k in range(frames))
+        for k in range(frames):
+            assert (dn / f"hmap_7_{k}.png").read_bytes() == (d1 / f"hmap_7_{k}.png").read_bytes(), (n_scenes, k)
+        for sc in many:
+            sc.close()
+    for k in (0, 5, 10):
+        cam = gpu.orbit_camera(base, cx, cy, radius, hang0, k, frames)
+        ofb, *_ = oracle.render(oracle.make_cfg(cam, params, 64, 64), heights, cmap)
+        assert (d1 / f"hmap_7_{k}.png").read_bytes() == gpu.png_encode(ofb), k
+    one.close()
+
+
+def test_two_streams_two_spherical_cameras(gpu, oracle):
+    """hmrm_render_rows_device from two HIP streams with two different spherical cameras, alternating
+    without a host sync in between: each stream has its own tables / counters (api.cpp StreamCtx), so
+    neither launch can read the other camera's sin/cos tables."""
+    import torch
+    rgb, cmap = scenes.small_maps(128, 128, 61)
+    params = gpu.SceneParams.make(0.0, 12.0, grid_width=1.0)
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    W, H = 320, 180
+    cams = [gpu.Camera.make(width=W, height=H, projection=2, hfov=gpu.degrees_to_rads(fov), hang=gpu.degrees_to_rads(hang),
+                            vang=gpu.degrees_to_rads(110), pos=pos, step_dist=0.25, bg=(7, 8, 9))
+            for fov, hang, pos in ((170, -45, (-40.0, 40.0, 50.0)), (120, 135, (170.0, -170.0, 35.0)))]
+    want = [oracle.render(oracle.make_cfg(c, params, 128, 128), heights, cmap)[0] for c in cams]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [[torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(6)] for _ in range(2)]
+    for rep in range(6):
+        for i in (0, 1):
+            # stream i alternates between the two cameras as well: slot reuse within one stream
+            cam = cams[(i + rep) % 2]
+            scene.render_rows_device(cam, bufs[i][rep].data_ptr(), W * 4, 0, H, stream=streams[i].cuda_stream)
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for i in (0, 1):
+            assert np.array_equal(bufs[i][rep].cpu().numpy(), want[(i + rep) % 2]), (rep, i)
+    assert scene.take_capped(streams[0].cuda_stream) == 0 and scene.take_capped(streams[1].cuda_stream) == 0
+    scene.close()
+
+
+def test_rows_device_reports_capped_rays(gpu):
+    """The asynchronous strip entry cannot return HMRM_E_NOTERM itself; hmrm_scene_take_capped does,
+    once, for the launches of that stream (the cap must never be silent)."""
+    import torch
+    rgb = np.zeros((8, 8, 3), dtype=np.uint8)
+    cmap = np.full((8, 8, 4), 255, dtype=np.uint8)
+    params = gpu.SceneParams.make(0.0, 4.0, grid_width=1.0)
+    cam = gpu.Camera.make(width=4, height=4, projection=3, hang=0.0, vang=0.0, pos=(4.0, -4.0, -3.0),
+                          ortho_width=0.5, step_dist=0.0, bg=(9, 8, 7))  # straight up, step 0: never ends
+    with env(HMRM_STEP_CAP=500):
+        scene = gpu.Scene(rgb, cmap, params)
+        buf = torch.zeros((4, 4, 4), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        for variant in KERNEL_VARIANTS:
+            with kernel_variant(variant):
+                scene.render_rows_device(cam, buf.data_ptr(), 16, 0, 4, stream=st)
+                scene.render_rows_device(cam, buf.data_ptr(), 16, 0, 2, stream=st)
+                with pytest.raises(gpu.HmrmError) as e:
+                    scene.take_capped(st)
+                assert e.value.code == gpu.HMRM_E_NOTERM and "24 ray(s)" in e.value.message, variant
+                assert scene.take_capped(st) == 0           # reported once
+        scene.close()
+
+
+def test_strips_over_rccl_two_gpus(gpu):
+    """bench.py --mode strips on two GPUs over RCCL (C2: cyclic 16-row bands, gather to rank 0, frame
+    checked against the single-GPU frame inside bench.py).  Skips on a one-GPU box."""
+    if gpu.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("strips", "frames"):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(root, "bench.py"),
+                            "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "C2", "--mode", mode,
+                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["value"] > 0
+
+
 def test_progressive_cycle_refresh(gpu, oracle):
     """`cycle n` (hmap.cpp:976-983): each call rewrites pixels p = cycle (mod n); n calls give the frame."""
     rgb, cmap = scenes.small_maps(64, 64, 55)
