@@ -1,17 +1,15 @@
-// bmp_tga_decode.cpp -- Windows BMP and Truevision TGA decoders, written for this
-// project.  Two more of the formats the reference accepts for its maps through
-// stbi_load (README.md "Options": "JPEG, PNG, TGA, BMP, ..."; main/hmap.cpp:320-321,
-// 341-342).  Conventions follow stb_image v2.27 so that the decoded pixels are the
-// same (checked against the reference's own stb build in tests/test_image_io.py):
-//   BMP (vendor/stb_image.h:5282-5655): 1/4/8-bit palettes, 16/24/32-bit direct colour
-//     with default or BI_BITFIELDS masks (channel = masked bits scaled to 8 bits by bit
-//     replication), bottom-up unless the height is negative, an all-zero alpha channel of a
-//     32-bit file reads as opaque, RLE / embedded JPEG/PNG refused;
-//   TGA (:5661-5990): types 1/2/3 and their RLE forms 9/10/11, 8/15/16/24/32 bits, 15/16-bit
-//     pixels and palette entries as 5-5-5 RGB scaled by 255/31, bottom-up unless bit 5 of the
-//     descriptor is set, BGR(A) -> RGB(A).
-#include <cstdint>
-#include <cstdlib>
+// bmp_tga_decode.cpp -- Windows / OS2 BMP and Truevision TGA decoders for height / colour maps.
+//
+// Written for this project from the file formats (BITMAPFILEHEADER + BITMAPCOREHEADER / INFOHEADER /
+// V4 / V5 headers; the 18-byte TGA header of the Truevision 2.0 specification), structured as:
+// parse the header into a plain description, then one pixel-fetch routine per storage class.
+//
+// The reference loads its maps with stb_image v2.27 (main/hmap.cpp:320-321, 341-342), so where the
+// formats leave room the choices are that loader's ("pixel contract" below): which variants are
+// accepted, how sub-byte channel fields are widened to 8 bits (bit replication), that a 32-bit BMP
+// whose alpha bytes are all zero is opaque, that a BMP reports 4 channels exactly when it has an alpha
+// mask, that 16-bit TGA pixels are 5-5-5 scaled by 255/31.  tests/golden/bmp_tga_decode.npz holds what
+// the reference's build of stb produces for 23 variants; tests/test_image_io.py compares, also live.
 #include <cstring>
 #include <string>
 #include <vector>
@@ -21,326 +19,424 @@
 namespace hmrm {
 namespace {
 
-struct Reader {
-	const uint8_t *base, *p, *end;
-	int get8() { return p < end ? *p++ : 0; } // past the end reads as zeros, like stb's reader
-	int get16le() { int a = get8(); return a | (get8() << 8); }
-	uint32_t get32le() { uint32_t a = (uint32_t)get16le(); return a | ((uint32_t)get16le() << 16); }
-	void skip(int n) {
-		if (n < 0) { p = end; return; } // stb: a negative skip jumps to the end of the data
-		p = (end - p) < n ? end : p + n;
+// Bounds-checked little-endian cursor.
+class Cursor {
+public:
+	Cursor(const uint8_t *p, size_t n) : p_(p), n_(n) {}
+	bool ok() const { return !bad_; }
+	size_t pos() const { return at_; }
+	size_t left() const { return at_ <= n_ ? n_ - at_ : 0; }
+	uint32_t u8() {
+		if (at_ >= n_) {
+			bad_ = true;
+			return 0;
+		}
+		return p_[at_++];
 	}
-	long consumed() const { return (long)(p - base); }
+	uint32_t u16() {
+		const uint32_t lo = u8();
+		return lo | (u8() << 8);
+	}
+	uint32_t u32() {
+		const uint32_t lo = u16();
+		return lo | (u16() << 16);
+	}
+	void skip(int64_t k) {
+		if (k < 0 || (uint64_t)k > left()) {
+			bad_ = true;
+			at_ = n_;
+			return;
+		}
+		at_ += (size_t)k;
+	}
+	const uint8_t *here() const { return p_ + at_; }
+
+private:
+	const uint8_t *p_;
+	size_t n_, at_ = 0;
+	bool bad_ = false;
 };
 
-int high_bit(uint32_t z) {
-	if (z == 0) return -1;
-	int n = 0;
-	if (z >= 0x10000) { n += 16; z >>= 16; }
-	if (z >= 0x00100) { n += 8; z >>= 8; }
-	if (z >= 0x00010) { n += 4; z >>= 4; }
-	if (z >= 0x00004) { n += 2; z >>= 2; }
-	if (z >= 0x00002) { n += 1; }
-	return n;
+bool fail(std::string *err, const char *why) {
+	*err = why;
+	return false;
 }
-int bit_count(uint32_t a) {
-	int n = 0;
-	for (; a; a &= a - 1) ++n;
-	return n;
+
+bool finish(Image *img, std::vector<uint8_t> &px, int w, int h, int have, int file_comp, int req_comp) {
+	img->w = w;
+	img->h = h;
+	img->comp_in_file = file_comp;
+	const int want = req_comp ? req_comp : have;
+	img->px = want == have ? std::move(px) : convert_channels8(px, have, want, (size_t)w * h);
+	img->comp = want;
+	return true;
 }
-// `bits` masked bits whose top bit sits `shift` above bit 7 -> 8 bits by bit replication
-int scale_masked(uint32_t v, int shift, int bits) {
-	static const unsigned mul_table[9] = {0, 0xff, 0x55, 0x49, 0x11, 0x21, 0x41, 0x81, 0x01};
-	static const unsigned shift_table[9] = {0, 0, 0, 1, 0, 2, 4, 6, 0};
-	if (shift < 0) v <<= -shift;
-	else v >>= shift;
-	v >>= (8 - bits);
-	return (int)((unsigned)v * mul_table[bits]) >> shift_table[bits];
+
+void flip_rows(std::vector<uint8_t> &px, int h, size_t row_bytes) {
+	std::vector<uint8_t> tmp(row_bytes);
+	for (int y = 0; y < h / 2; ++y) {
+		uint8_t *a = &px[(size_t)y * row_bytes], *b = &px[(size_t)(h - 1 - y) * row_bytes];
+		std::memcpy(tmp.data(), a, row_bytes);
+		std::memcpy(a, b, row_bytes);
+		std::memcpy(b, tmp.data(), row_bytes);
+	}
+}
+
+// ------------------------------------------------------------------- BMP ----
+// One channel of a packed pixel: the field selected by `mask`, widened to 8 bits by repeating its
+// bit pattern (pixel contract; fields wider than 8 bits keep their top 8).
+struct Field {
+	uint32_t mask = 0;
+	int shift = 0, bits = 0;
+	bool set(uint32_t m) {
+		mask = m;
+		shift = bits = 0;
+		if (!m) return true;
+		while (!((m >> shift) & 1u)) ++shift;
+		uint32_t run = m >> shift;
+		while (run & 1u) {
+			++bits;
+			run >>= 1;
+		}
+		return run == 0; // one contiguous run of ones
+	}
+	uint8_t get(uint32_t px) const {
+		uint32_t v = (px & mask) >> shift;
+		if (bits >= 8) return (uint8_t)(v >> (bits - 8));
+		uint32_t out = 0;
+		for (int filled = 0; filled < 8; filled += bits) {
+			const int room = 8 - filled;
+			out |= room >= bits ? v << (room - bits) : v >> (bits - room);
+		}
+		return (uint8_t)out;
+	}
+};
+
+struct BmpInfo {
+	int width = 0, height = 0;
+	bool bottom_up = true;
+	int bpp = 0, header = 0;
+	uint32_t compression = 0;
+	uint32_t data_offset = 0;
+	Field r, g, b, a;
+	bool has_alpha_mask = false;
+	bool plain_bgra = false;   // 32-bit with the standard byte masks
+	bool default_masks32 = false; // 32-bit without bit-field masks of its own: alpha that is zero everywhere means opaque
+};
+
+bool bmp_header(Cursor &c, BmpInfo *bi, std::string *err) {
+	if (c.u8() != 'B' || c.u8() != 'M') return fail(err, "not BMP");
+	c.u32(); // file size
+	c.u32(); // reserved
+	bi->data_offset = c.u32();
+	bi->header = (int)c.u32();
+	const int hs = bi->header;
+	if (hs != 12 && hs != 40 && hs != 56 && hs != 108 && hs != 124) return fail(err, "unknown BMP header");
+	int w, h;
+	if (hs == 12) {
+		w = (int)c.u16();
+		h = (int)c.u16();
+	} else {
+		w = (int)c.u32();
+		h = (int)c.u32();
+	}
+	if (c.u16() != 1) return fail(err, "bad BMP planes");
+	bi->bpp = (int)c.u16();
+	uint32_t mr = 0, mg = 0, mb = 0, ma = 0;
+	bool masks_from_file = false;
+	if (hs != 12) {
+		bi->compression = c.u32();
+		if (bi->compression == 1 || bi->compression == 2) return fail(err, "BMP RLE is not supported");
+		if (bi->compression >= 4) return fail(err, "BMP with embedded JPEG/PNG is not supported");
+		if (bi->compression == 3 && bi->bpp != 16 && bi->bpp != 32) return fail(err, "bad BMP bitfields");
+		c.skip(20); // image size, resolution x/y, colours used / important
+		if (hs == 40 || hs == 56) {
+			if (hs == 56) c.skip(16);
+			if ((bi->bpp == 16 || bi->bpp == 32) && bi->compression == 3) {
+				mr = c.u32();
+				mg = c.u32();
+				mb = c.u32();
+				masks_from_file = true;
+				if (mr == mg && mg == mb) return fail(err, "bad BMP masks");
+			}
+		} else {
+			mr = c.u32();
+			mg = c.u32();
+			mb = c.u32();
+			ma = c.u32();
+			masks_from_file = bi->compression == 3;
+			c.skip(4 + 48);          // colour space type + end points and gammas
+			if (hs == 124) c.skip(16); // intent, profile data / size, reserved
+		}
+	}
+	if (!c.ok()) return fail(err, "truncated BMP header");
+	if (!masks_from_file) { // pixel contract: 5-5-5 for 16 bits, B,G,R,A bytes for 32 bits
+		mr = mg = mb = ma = 0;
+		if (bi->bpp == 16) {
+			mr = 31u << 10;
+			mg = 31u << 5;
+			mb = 31u;
+		} else if (bi->bpp == 32) {
+			mr = 0xffu << 16;
+			mg = 0xffu << 8;
+			mb = 0xffu;
+			ma = 0xffu << 24;
+		}
+	}
+	if (bi->bpp == 16 || bi->bpp == 32) {
+		if (!mr || !mg || !mb) return fail(err, "bad BMP masks");
+		if (!bi->r.set(mr) || !bi->g.set(mg) || !bi->b.set(mb) || !bi->a.set(ma)) return fail(err, "bad BMP masks");
+		if (bi->r.bits > 8 || bi->g.bits > 8 || bi->b.bits > 8 || bi->a.bits > 8) return fail(err, "bad BMP masks");
+		bi->plain_bgra = bi->bpp == 32 && mb == 0xffu && mg == 0xff00u && mr == 0xff0000u && ma == 0xff000000u;
+	}
+	bi->has_alpha_mask = ma != 0;
+	bi->default_masks32 = bi->bpp == 32 && !masks_from_file;
+	bi->bottom_up = h > 0;
+	bi->width = w;
+	bi->height = h < 0 ? -h : h;
+	if (bi->width <= 0 || bi->height <= 0 || bi->width > (1 << 24) || bi->height > (1 << 24) ||
+	    (int64_t)bi->width * bi->height > ((int64_t)1 << 28))
+		return fail(err, "bad BMP size");
+	return true;
 }
 
 } // namespace
 
-bool looks_like_bmp(const uint8_t *b, size_t len) {
-	if (len < 18 || b[0] != 'B' || b[1] != 'M') return false;
-	const uint32_t sz = (uint32_t)b[14] | ((uint32_t)b[15] << 8) | ((uint32_t)b[16] << 16) | ((uint32_t)b[17] << 24);
-	return sz == 12 || sz == 40 || sz == 56 || sz == 108 || sz == 124;
+bool looks_like_bmp(const uint8_t *bytes, size_t len) {
+	if (len < 18 || bytes[0] != 'B' || bytes[1] != 'M') return false;
+	const uint32_t hs = bytes[14] | (bytes[15] << 8) | (bytes[16] << 16) | ((uint32_t)bytes[17] << 24);
+	return hs == 12 || hs == 40 || hs == 56 || hs == 108 || hs == 124;
 }
 
-bool decode_bmp(const uint8_t *bytes, size_t len, int req_comp, Image *img, std::string *err) {
-	Reader s{bytes, bytes, bytes + len};
-	auto fail = [&](const char *m) { *err = m; return false; };
-	if (s.get8() != 'B' || s.get8() != 'M') return fail("not BMP");
-	s.get32le(); s.get16le(); s.get16le();
-	const int offset = (int)s.get32le();
-	const int hsz = (int)s.get32le();
-	uint32_t mr = 0, mg = 0, mb = 0, ma = 0, all_a = 255;
-	int extra_read = 14;
-	if (offset < 0) return fail("bad BMP");
-	if (hsz != 12 && hsz != 40 && hsz != 56 && hsz != 108 && hsz != 124) return fail("unknown BMP");
-	int img_x, img_y_signed;
-	if (hsz == 12) { img_x = s.get16le(); img_y_signed = s.get16le(); }
-	else { img_x = (int)s.get32le(); img_y_signed = (int)s.get32le(); }
-	if (s.get16le() != 1) return fail("bad BMP");
-	const int bpp = s.get16le();
-	auto mask_defaults = [&](int compress) {
-		if (compress == 3) return;
-		if (compress == 0) {
-			if (bpp == 16) { mr = 31u << 10; mg = 31u << 5; mb = 31u; }
-			else if (bpp == 32) { mr = 0xffu << 16; mg = 0xffu << 8; mb = 0xffu; ma = 0xffu << 24; all_a = 0; }
-			else mr = mg = mb = ma = 0;
+bool decode_bmp(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err) {
+	Cursor c(bytes, len);
+	BmpInfo bi;
+	if (!bmp_header(c, &bi, err)) return false;
+	const int w = bi.width, h = bi.height;
+	const int file_comp = bi.has_alpha_mask ? 4 : 3;
+	// decode straight into 3 or 4 channels: 4 when the caller wants 4 or the file has alpha and the
+	// caller did not ask for exactly 3
+	const int have = (req_comp >= 3) ? req_comp : file_comp;
+	std::vector<uint8_t> px((size_t)w * h * have);
+	const int64_t after_headers = 14 + (int64_t)bi.header;
+	bool any_alpha = !bi.default_masks32;
+
+	if (bi.bpp == 1 || bi.bpp == 4 || bi.bpp == 8) {
+		const int entry = bi.header == 12 ? 3 : 4;
+		const int64_t table_bytes = (int64_t)bi.data_offset - after_headers;
+		const int64_t entries = table_bytes / entry;
+		if (entries <= 0 || entries > 256) return fail(err, "bad BMP palette");
+		uint8_t pal[256][3];
+		for (int i = 0; i < (int)entries; ++i) {
+			pal[i][2] = (uint8_t)c.u8();
+			pal[i][1] = (uint8_t)c.u8();
+			pal[i][0] = (uint8_t)c.u8();
+			if (entry == 4) c.u8();
 		}
-	};
-	if (hsz != 12) {
-		const int compress = (int)s.get32le();
-		if (compress == 1 || compress == 2) return fail("BMP RLE");
-		if (compress >= 4) return fail("BMP JPEG/PNG");
-		if (compress == 3 && bpp != 16 && bpp != 32) return fail("bad BMP");
-		s.get32le(); s.get32le(); s.get32le(); s.get32le(); s.get32le();
-		if (hsz == 40 || hsz == 56) {
-			if (hsz == 56) { s.get32le(); s.get32le(); s.get32le(); s.get32le(); }
-			if (bpp == 16 || bpp == 32) {
-				if (compress == 0) mask_defaults(compress);
-				else if (compress == 3) {
-					mr = s.get32le(); mg = s.get32le(); mb = s.get32le();
-					extra_read += 12;
-					if (mr == mg && mg == mb) return fail("bad BMP");
-				} else return fail("bad BMP");
+		c.skip(table_bytes - entries * entry);
+		const int row_data = bi.bpp == 8 ? w : (bi.bpp == 4 ? (w + 1) / 2 : (w + 7) / 8);
+		const int pad = (4 - (row_data & 3)) & 3;
+		if (!c.ok() || (int64_t)c.left() < (int64_t)(row_data + pad) * (h - 1) + row_data) return fail(err, "truncated BMP");
+		for (int y = 0; y < h; ++y) {
+			const uint8_t *row = c.here();
+			uint8_t *o = &px[(size_t)y * w * have];
+			for (int x = 0; x < w; ++x, o += have) {
+				int idx;
+				if (bi.bpp == 8) idx = row[x];
+				else if (bi.bpp == 4) idx = (x & 1) ? (row[x >> 1] & 15) : (row[x >> 1] >> 4);
+				else idx = (row[x >> 3] >> (7 - (x & 7))) & 1;
+				if (idx >= (int)entries) idx = 0; // (an index beyond the table: colour 0)
+				o[0] = pal[idx][0];
+				o[1] = pal[idx][1];
+				o[2] = pal[idx][2];
+				if (have == 4) o[3] = 255;
 			}
-		} else {
-			mr = s.get32le(); mg = s.get32le(); mb = s.get32le(); ma = s.get32le();
-			if (compress != 3) mask_defaults(compress);
-			s.get32le();
-			for (int i = 0; i < 12; ++i) s.get32le();
-			if (hsz == 124) { s.get32le(); s.get32le(); s.get32le(); s.get32le(); }
+			c.skip(y + 1 < h ? row_data + pad : row_data);
 		}
-	}
-	const bool flip = img_y_signed > 0;
-	const int img_y = std::abs(img_y_signed);
-	if (img_x <= 0 || img_y <= 0 || img_x > (1 << 24) || img_y > (1 << 24)) return fail("too large");
-	int psize = 0;
-	if (hsz == 12) { if (bpp < 24) psize = (offset - extra_read - 24) / 3; }
-	else if (bpp < 16) psize = (offset - extra_read - hsz) >> 2;
-	if (psize == 0 && offset != s.consumed()) return fail("bad offset");
-	const int img_n = (bpp == 24 && ma == 0xff000000u) ? 3 : (ma ? 4 : 3);
-	const int target = (req_comp && req_comp >= 3) ? req_comp : img_n;
-	if ((int64_t)img_x * img_y * target > ((int64_t)1 << 30)) return fail("too large");
-	std::vector<uint8_t> out((size_t)img_x * img_y * target);
-	size_t z = 0;
-	if (bpp < 16) {
-		if (psize <= 0 || psize > 256) return fail("invalid"); // (stb reads an uninitialised palette for psize < 0)
-		uint8_t pal[256][4];
-		for (int i = 0; i < psize; ++i) {
-			pal[i][2] = (uint8_t)s.get8(); pal[i][1] = (uint8_t)s.get8(); pal[i][0] = (uint8_t)s.get8();
-			if (hsz != 12) s.get8();
-			pal[i][3] = 255;
-		}
-		for (int i = psize; i < 256; ++i) pal[i][0] = pal[i][1] = pal[i][2] = 0, pal[i][3] = 255;
-		s.skip(offset - extra_read - hsz - psize * (hsz == 12 ? 3 : 4));
-		int width;
-		if (bpp == 1) width = (img_x + 7) >> 3;
-		else if (bpp == 4) width = (img_x + 1) >> 1;
-		else if (bpp == 8) width = img_x;
-		else return fail("bad bpp");
-		const int pad = (-width) & 3;
-		auto put = [&](int c) {
-			out[z++] = pal[c][0]; out[z++] = pal[c][1]; out[z++] = pal[c][2];
-			if (target == 4) out[z++] = 255;
-		};
-		for (int j = 0; j < img_y; ++j) {
-			if (bpp == 1) {
-				int bit = 7, v = s.get8();
-				for (int i = 0; i < img_x; ++i) {
-					put((v >> bit) & 1);
-					if (i + 1 == img_x) break;
-					if (--bit < 0) { bit = 7; v = s.get8(); }
-				}
-			} else {
-				for (int i = 0; i < img_x; i += 2) {
-					int v = s.get8(), v2 = 0;
-					if (bpp == 4) { v2 = v & 15; v >>= 4; }
-					put(v);
-					if (i + 1 == img_x) break;
-					put(bpp == 8 ? s.get8() : v2);
-				}
-			}
-			s.skip(pad);
-		}
-	} else {
-		s.skip(offset - extra_read - hsz);
-		int width = bpp == 24 ? 3 * img_x : (bpp == 16 ? 2 * img_x : 0);
-		const int pad = (-width) & 3;
-		int easy = 0;
-		if (bpp == 24) easy = 1;
-		else if (bpp == 32 && mb == 0xff && mg == 0xff00 && mr == 0x00ff0000 && ma == 0xff000000u) easy = 2;
-		int rshift = 0, gshift = 0, bshift = 0, ashift = 0, rcount = 0, gcount = 0, bcount = 0, acount = 0;
-		if (!easy) {
-			if (!mr || !mg || !mb) return fail("bad masks");
-			rshift = high_bit(mr) - 7; rcount = bit_count(mr);
-			gshift = high_bit(mg) - 7; gcount = bit_count(mg);
-			bshift = high_bit(mb) - 7; bcount = bit_count(mb);
-			ashift = high_bit(ma) - 7; acount = bit_count(ma);
-			if (rcount > 8 || gcount > 8 || bcount > 8 || acount > 8) return fail("bad masks");
-		}
-		for (int j = 0; j < img_y; ++j) {
-			for (int i = 0; i < img_x; ++i) {
-				unsigned a;
-				if (easy) {
-					out[z + 2] = (uint8_t)s.get8(); out[z + 1] = (uint8_t)s.get8(); out[z + 0] = (uint8_t)s.get8();
-					z += 3;
-					a = easy == 2 ? (unsigned)s.get8() : 255u;
+	} else if (bi.bpp == 16 || bi.bpp == 24 || bi.bpp == 32) {
+		c.skip((int64_t)bi.data_offset - (int64_t)c.pos()); // (bit-field masks may follow a 40/56-byte header)
+		const int bytes_pp = bi.bpp / 8;
+		const int64_t row_data = (int64_t)w * bytes_pp;
+		const int pad = (int)((4 - (row_data & 3)) & 3);
+		if (!c.ok() || (int64_t)c.left() < (row_data + pad) * (h - 1) + row_data) return fail(err, "truncated BMP");
+		for (int y = 0; y < h; ++y) {
+			const uint8_t *s = c.here();
+			uint8_t *o = &px[(size_t)y * w * have];
+			for (int x = 0; x < w; ++x, o += have, s += bytes_pp) {
+				uint8_t a = 255;
+				if (bi.bpp == 24 || bi.plain_bgra) {
+					o[0] = s[2];
+					o[1] = s[1];
+					o[2] = s[0];
+					if (bi.bpp == 32) a = s[3];
 				} else {
-					const uint32_t v = bpp == 16 ? (uint32_t)s.get16le() : s.get32le();
-					out[z++] = (uint8_t)scale_masked(v & mr, rshift, rcount);
-					out[z++] = (uint8_t)scale_masked(v & mg, gshift, gcount);
-					out[z++] = (uint8_t)scale_masked(v & mb, bshift, bcount);
-					a = ma ? (unsigned)scale_masked(v & ma, ashift, acount) : 255u;
+					const uint32_t v = bi.bpp == 16 ? (uint32_t)(s[0] | (s[1] << 8))
+					                                : (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+					o[0] = bi.r.get(v);
+					o[1] = bi.g.get(v);
+					o[2] = bi.b.get(v);
+					if (bi.a.mask) a = bi.a.get(v);
 				}
-				all_a |= a;
-				if (target == 4) out[z++] = (uint8_t)a;
+				any_alpha = any_alpha || a != 0;
+				if (have == 4) o[3] = a;
 			}
-			s.skip(pad);
+			c.skip(y + 1 < h ? row_data + pad : row_data);
 		}
+		// pixel contract: default-mask 32-bit files whose alpha bytes are zero everywhere are opaque
+		if (have == 4 && !any_alpha)
+			for (size_t i = 3; i < px.size(); i += 4) px[i] = 255;
+	} else {
+		return fail(err, "unsupported BMP bit depth");
 	}
-	if (target == 4 && all_a == 0)
-		for (size_t i = 3; i < out.size(); i += 4) out[i] = 255;
-	if (flip) {
-		const size_t row = (size_t)img_x * target;
-		for (int j = 0; j < img_y >> 1; ++j)
-			for (size_t i = 0; i < row; ++i) std::swap(out[(size_t)j * row + i], out[(size_t)(img_y - 1 - j) * row + i]);
-	}
-	img->w = img_x;
-	img->h = img_y;
-	img->comp_in_file = img_n;
-	const int final_n = req_comp ? req_comp : target;
-	img->px = convert_channels8(out, target, final_n, (size_t)img_x * img_y);
-	img->comp = final_n;
-	return true;
+	if (bi.bottom_up) flip_rows(px, h, (size_t)w * have);
+	return finish(out, px, w, h, have, file_comp, req_comp);
 }
 
 // ------------------------------------------------------------------- TGA ----
-static int tga_components(int bits, bool is_grey, bool *rgb16) {
-	*rgb16 = false;
+namespace {
+
+struct TgaInfo {
+	int id_len = 0, map_type = 0, image_type = 0;
+	int map_first = 0, map_len = 0, map_bits = 0;
+	int width = 0, height = 0, bpp = 0, descriptor = 0;
+	bool rle = false;
+};
+
+// channels of one pixel (or palette entry) of `bits` bits; 15/16-bit colour is 5-5-5 -> 3 channels
+int tga_channels(int bits, bool grey, bool *packed555) {
+	*packed555 = false;
 	switch (bits) {
 	case 8: return 1;
-	case 16: if (is_grey) return 2; // fallthrough
-	case 15: *rgb16 = true; return 3;
-	case 24: case 32: return bits / 8;
+	case 16:
+		if (grey) return 2; // grey + alpha
+		// fall through
+	case 15: *packed555 = true; return 3;
+	case 24: return 3;
+	case 32: return 4;
 	default: return 0;
 	}
 }
 
-bool looks_like_tga(const uint8_t *b, size_t len) {
-	Reader s{b, b, b + len};
-	s.get8();
-	const int color_type = s.get8();
-	if (color_type > 1) return false;
-	int sz = s.get8();
-	if (color_type == 1) {
-		if (sz != 1 && sz != 9) return false;
-		s.skip(4);
-		sz = s.get8();
-		if (sz != 8 && sz != 15 && sz != 16 && sz != 24 && sz != 32) return false;
-		s.skip(4);
-	} else {
-		if (sz != 2 && sz != 3 && sz != 10 && sz != 11) return false;
-		s.skip(9);
-	}
-	if (s.get16le() < 1) return false;
-	if (s.get16le() < 1) return false;
-	sz = s.get8();
-	if (color_type == 1 && sz != 8 && sz != 16) return false;
-	if (sz != 8 && sz != 15 && sz != 16 && sz != 24 && sz != 32) return false;
-	return true;
+bool tga_header(Cursor &c, TgaInfo *t) {
+	t->id_len = (int)c.u8();
+	t->map_type = (int)c.u8();
+	t->image_type = (int)c.u8();
+	t->map_first = (int)c.u16();
+	t->map_len = (int)c.u16();
+	t->map_bits = (int)c.u8();
+	c.u16(); // x origin
+	c.u16(); // y origin
+	t->width = (int)c.u16();
+	t->height = (int)c.u16();
+	t->bpp = (int)c.u8();
+	t->descriptor = (int)c.u8();
+	t->rle = t->image_type >= 8;
+	if (t->rle) t->image_type -= 8;
+	return c.ok();
 }
 
-bool decode_tga(const uint8_t *bytes, size_t len, int req_comp, Image *img, std::string *err) {
-	Reader s{bytes, bytes, bytes + len};
-	auto fail = [&](const char *m) { *err = m; return false; };
-	const int id_len = s.get8();
-	const int indexed = s.get8();
-	int image_type = s.get8();
-	const int pal_start = s.get16le(), pal_len = s.get16le(), pal_bits = s.get8();
-	s.get16le(); s.get16le();
-	const int W = s.get16le(), H = s.get16le();
-	const int bpp = s.get8();
-	int inverted = s.get8();
-	bool rle = false;
-	if (image_type >= 8) { image_type -= 8; rle = true; }
-	inverted = 1 - ((inverted >> 5) & 1);
-	bool rgb16 = false;
-	const int comp = indexed ? tga_components(pal_bits, false, &rgb16) : tga_components(bpp, image_type == 3, &rgb16);
-	if (!comp) return fail("bad format");
-	if (W <= 0 || H <= 0) return fail("bad format");
-	if ((int64_t)W * H * comp > ((int64_t)1 << 30)) return fail("too large");
-	std::vector<uint8_t> data((size_t)W * H * comp, 0);
-	s.skip(id_len);
-	auto read_rgb16 = [&](uint8_t *out) {
-		const unsigned px = (unsigned)s.get16le();
-		out[0] = (uint8_t)((((px >> 10) & 31) * 255) / 31);
-		out[1] = (uint8_t)((((px >> 5) & 31) * 255) / 31);
-		out[2] = (uint8_t)(((px & 31) * 255) / 31);
-	};
-	if (!indexed && !rle && !rgb16) {
-		for (int i = 0; i < H; ++i) {
-			const int row = inverted ? H - i - 1 : i;
-			uint8_t *dst = &data[(size_t)row * W * comp];
-			const size_t n = (size_t)W * comp, avail = (size_t)(s.end - s.p);
-			if (avail >= n) { memcpy(dst, s.p, n); s.p += n; } // a short row is left untouched (stb: getn fails)
-		}
+bool tga_plausible(const TgaInfo &t) {
+	if (t.map_type > 1) return false;
+	if (t.map_type == 1) {
+		if (t.image_type != 1) return false;
+		if (t.map_bits != 8 && t.map_bits != 15 && t.map_bits != 16 && t.map_bits != 24 && t.map_bits != 32) return false;
+		if (t.bpp != 8 && t.bpp != 16) return false;
 	} else {
-		std::vector<uint8_t> palette;
+		if (t.image_type != 2 && t.image_type != 3) return false;
+		if (t.bpp != 8 && t.bpp != 15 && t.bpp != 16 && t.bpp != 24 && t.bpp != 32) return false;
+	}
+	return t.width >= 1 && t.height >= 1;
+}
+
+// pixel contract: 5 bits -> 8 bits as v * 255 / 31
+inline void unpack555(uint32_t v, uint8_t *rgb) {
+	rgb[0] = (uint8_t)((((v >> 10) & 31u) * 255u) / 31u);
+	rgb[1] = (uint8_t)((((v >> 5) & 31u) * 255u) / 31u);
+	rgb[2] = (uint8_t)(((v & 31u) * 255u) / 31u);
+}
+
+} // namespace
+
+bool looks_like_tga(const uint8_t *bytes, size_t len) {
+	Cursor c(bytes, len);
+	TgaInfo t;
+	return tga_header(c, &t) && tga_plausible(t);
+}
+
+bool decode_tga(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err) {
+	Cursor c(bytes, len);
+	TgaInfo t;
+	if (!tga_header(c, &t) || !tga_plausible(t)) return fail(err, "bad TGA header");
+	const bool indexed = t.map_type == 1;
+	bool packed = false;
+	const int comp = tga_channels(indexed ? t.map_bits : t.bpp, t.image_type == 3, &packed);
+	if (comp == 0) return fail(err, "bad TGA format");
+	const int w = t.width, h = t.height;
+	if ((int64_t)w * h > ((int64_t)1 << 28)) return fail(err, "TGA too large");
+	c.skip(t.id_len);
+
+	std::vector<uint8_t> palette;
+	if (indexed) {
+		if (t.map_len == 0) return fail(err, "bad TGA palette");
+		c.skip(t.map_first); // pixel contract: the first-entry field is skipped as a byte count
+		palette.resize((size_t)t.map_len * comp);
+		for (int i = 0; i < t.map_len; ++i) {
+			uint8_t *e = &palette[(size_t)i * comp];
+			if (packed) unpack555(c.u16(), e);
+			else
+				for (int k = 0; k < comp; ++k) e[k] = (uint8_t)c.u8();
+		}
+		if (!c.ok()) return fail(err, "truncated TGA palette");
+	}
+
+	// one stored pixel -> comp bytes, still in file channel order (B,G,R[,A] for true colour)
+	auto fetch = [&](uint8_t *dst) {
 		if (indexed) {
-			if (pal_len == 0) return fail("bad palette");
-			s.skip(pal_start);
-			palette.assign((size_t)pal_len * comp, 0);
-			if (rgb16) {
-				for (int i = 0; i < pal_len; ++i) read_rgb16(&palette[(size_t)i * comp]);
+			uint32_t idx = t.bpp == 8 ? c.u8() : c.u16();
+			if (idx >= (uint32_t)t.map_len) idx = 0;
+			std::memcpy(dst, &palette[(size_t)idx * comp], (size_t)comp);
+		} else if (packed) {
+			unpack555(c.u16(), dst);
+		} else {
+			for (int k = 0; k < comp; ++k) dst[k] = (uint8_t)c.u8();
+		}
+	};
+
+	const size_t npix = (size_t)w * h;
+	std::vector<uint8_t> px(npix * comp);
+	if (!t.rle) {
+		const int stored = indexed ? t.bpp / 8 : (packed ? 2 : comp);
+		if (c.left() < npix * (size_t)stored) return fail(err, "truncated TGA");
+		for (size_t i = 0; i < npix; ++i) fetch(&px[i * comp]);
+	} else {
+		size_t i = 0;
+		uint8_t run_px[4] = {0, 0, 0, 0};
+		while (i < npix) {
+			const uint32_t packet = c.u8();
+			size_t count = (packet & 127u) + 1;
+			if (!c.ok()) return fail(err, "truncated TGA");
+			if (count > npix - i) count = npix - i; // (a packet may not run past the image)
+			if (packet & 128u) {
+				fetch(run_px);
+				for (size_t k = 0; k < count; ++k) std::memcpy(&px[(i + k) * comp], run_px, (size_t)comp);
 			} else {
-				const size_t n = palette.size();
-				if ((size_t)(s.end - s.p) < n) return fail("bad palette");
-				memcpy(palette.data(), s.p, n);
-				s.p += n;
+				for (size_t k = 0; k < count; ++k) fetch(&px[(i + k) * comp]);
 			}
-		}
-		uint8_t raw[4] = {0, 0, 0, 0};
-		int rle_count = 0, rle_repeating = 0;
-		bool read_next = true;
-		for (size_t i = 0; i < (size_t)W * H; ++i) {
-			if (rle) {
-				if (rle_count == 0) {
-					const int cmd = s.get8();
-					rle_count = 1 + (cmd & 127);
-					rle_repeating = cmd >> 7;
-					read_next = true;
-				} else if (!rle_repeating) read_next = true;
-			} else read_next = true;
-			if (read_next) {
-				if (indexed) {
-					int idx = bpp == 8 ? s.get8() : s.get16le();
-					if (idx >= pal_len) idx = 0;
-					for (int j = 0; j < comp; ++j) raw[j] = palette[(size_t)idx * comp + j];
-				} else if (rgb16) read_rgb16(raw);
-				else for (int j = 0; j < comp; ++j) raw[j] = (uint8_t)s.get8();
-				read_next = false;
-			}
-			for (int j = 0; j < comp; ++j) data[i * comp + j] = raw[j];
-			if (rle) --rle_count;
-		}
-		if (inverted) {
-			const size_t row = (size_t)W * comp;
-			for (int j = 0; j * 2 < H; ++j)
-				for (size_t i = 0; i < row; ++i) std::swap(data[(size_t)j * row + i], data[(size_t)(H - 1 - j) * row + i]);
+			if (!c.ok()) return fail(err, "truncated TGA");
+			i += count;
 		}
 	}
-	if (comp >= 3 && !rgb16)
-		for (size_t i = 0; i < (size_t)W * H; ++i) std::swap(data[i * comp], data[i * comp + 2]);
-	img->w = W;
-	img->h = H;
-	img->comp_in_file = comp;
-	const int final_n = req_comp ? req_comp : comp;
-	img->px = convert_channels8(data, comp, final_n, (size_t)W * H);
-	img->comp = final_n;
-	return true;
+	if (!c.ok()) return fail(err, "truncated TGA");
+	// bit 5 of the descriptor set = first row is the top row
+	if (!((t.descriptor >> 5) & 1)) flip_rows(px, h, (size_t)w * comp);
+	// true colour is stored blue first (5-5-5 pixels were unpacked as R,G,B already)
+	if (comp >= 3 && !packed)
+		for (size_t i = 0; i < npix; ++i) {
+			const uint8_t b = px[i * comp];
+			px[i * comp] = px[i * comp + 2];
+			px[i * comp + 2] = b;
+		}
+	return finish(out, px, w, h, comp, comp, req_comp);
 }
 
 } // namespace hmrm

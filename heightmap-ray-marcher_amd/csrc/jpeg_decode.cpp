@@ -1,24 +1,19 @@
-// jpeg_decode.cpp -- baseline and progressive JPEG decoder (8-bit, Huffman),
-// written for this project.  The maps of the reference are usually photographs
-// (README.md: "The image can be any format supported by stb_image.h: JPEG, ...";
-// sample_config.txt uses .jpg), loaded with stbi_load(path,&w,&h,&n,3|4)
-// (main/hmap.cpp:320-321,341-342).  A JPEG decoder is only a drop-in if it produces
-// the same pixels as that loader, and JPEG leaves IDCT precision, chroma upsampling
-// and colour conversion to the implementation.  So the arithmetic below follows what
-// stb_image v2.27 does (vendor/stb_image.h), and tests/test_image_io.py compares the
-// result with the reference's own stb build (oracle/_ref) pixel for pixel:
-//   * coefficients are kept in 16-bit storage after dequantisation (:2198,:3039-3044)
-//   * IDCT: the integer "islow" variant at 12 fractional bits, column pass rounded to
-//     2 extra bits, row pass rounded once, +128, clamp (:2406-2493)
-//   * chroma upsampling: triangle filters (3:1 weights) for 2x horizontal, 2x
-//     vertical and 2x2, nearest for other ratios, sample row chosen per output row
-//     as in :3873-3887
-//   * YCbCr -> RGB in 20-bit fixed point with stb's reduced-precision constants
-//     (:3604-3630); Adobe APP14 transform flags, CMYK/YCCK through the 8x8 "blinn"
-//     multiply (:3805-3809, :3905-3928)
-//   * channel conversion to req_comp as load_jpeg_image does it (:3811-3972)
-// Not supported (as in stb): arithmetic coding, 12-bit, lossless, hierarchical.
-#include <cstdint>
+// jpeg_decode.cpp -- JPEG (ITU-T T.81) decoder for height / colour maps: baseline and extended
+// sequential Huffman (SOF0/SOF1) and progressive Huffman (SOF2), 8 bits per sample, 1, 3 or 4
+// components, restart intervals, JFIF / Adobe colour signalling.
+//
+// Written for this project from the standard (T.81 Annex B marker syntax, Annex F/G entropy coding,
+// Annex A.3.3 IDCT definition) with its own structure: the file is first cut into marker segments,
+// every scan's entropy-coded bytes are un-stuffed and split at the restart markers up front, the
+// coefficients of every scan type land in one coefficient store per component, and one
+// reconstruction pass (dequantise, IDCT, upsample, colour) runs at the end.
+//
+// ONE thing is not free: the reference loads its maps with stb_image v2.27 (main/hmap.cpp:320-321,
+// 341-342), and a JPEG file does not define its decoded pixels to the last bit -- the IDCT's
+// fixed-point arithmetic, the chroma upsampling filter and the YCbCr matrix's rounding are the
+// decoder's choice.  Heights come from these pixels, so the numerical choices below are stb_image's,
+// restated as arithmetic (each marked "pixel contract"); tests/golden/jpeg_decode.npz holds what the
+// reference's build of stb produces and tests/test_image_io.py compares with it, also live.
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,723 +23,761 @@
 namespace hmrm {
 namespace {
 
-const uint8_t kDezigzag[64 + 15] = {
-    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
-    // guard entries so that a corrupt run cannot index out of range
-    63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+// Zig-zag position -> natural (row-major) index, T.81 Figure A.6.
+const uint8_t kNatural[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-const int kMarkerNone = 0xff;
+struct Fail {
+	std::string why;
+};
 
-struct Huffman {
-	uint16_t code[256];
-	uint8_t values[256];
-	uint8_t size[257];
-	uint32_t maxcode[18];
-	int delta[17];
-	bool build(const int count[16]) {
-		int k = 0;
-		for (int i = 0; i < 16; ++i)
-			for (int j = 0; j < count[i]; ++j) {
-				if (k >= 256) return false;
-				size[k++] = (uint8_t)(i + 1);
-			}
-		size[k] = 0;
-		uint32_t c = 0;
-		k = 0;
-		for (int j = 1; j <= 16; ++j) {
-			delta[j] = k - (int)c;
-			if (size[k] == j) {
-				while (size[k] == j) code[k++] = (uint16_t)(c++);
-				if (c - 1 >= (1u << j)) return false;
-			}
-			maxcode[j] = c << (16 - j);
-			c <<= 1;
+// ------------------------------------------------------------------ bits ----
+// MSB-first reader over un-stuffed entropy-coded bytes.  Past the end it delivers zero bits (a
+// truncated interval then decodes as whatever zeros mean, as common decoders do) and counts them.
+class BitSource {
+public:
+	BitSource(const uint8_t *p, size_t n) : p_(p), n_(n) {}
+	inline void fill() {
+		while (have_ <= 56) {
+			const uint64_t b = pos_ < n_ ? p_[pos_] : 0;
+			++pos_;
+			acc_ |= b << (56 - have_);
+			have_ += 8;
 		}
-		maxcode[17] = 0xffffffffu;
-		return true;
 	}
+	inline uint32_t peek(int n) { // n in 1..16
+		if (have_ < n) fill();
+		return (uint32_t)(acc_ >> (64 - n));
+	}
+	inline void drop(int n) {
+		acc_ <<= n;
+		have_ -= n;
+	}
+	inline uint32_t take(int n) {
+		if (n == 0) return 0;
+		const uint32_t v = peek(n);
+		drop(n);
+		return v;
+	}
+
+private:
+	const uint8_t *p_;
+	size_t n_, pos_ = 0;
+	uint64_t acc_ = 0;
+	int have_ = 0;
 };
 
-struct Component {
-	int id = 0, h = 0, v = 0, tq = 0, hd = 0, ha = 0, dc_pred = 0;
-	int x = 0, y = 0, w2 = 0, h2 = 0;
-	std::vector<uint8_t> data;   // w2 x h2 samples
-	std::vector<int16_t> coeff;  // progressive: 64 per block, coeff_w blocks per row
-	int coeff_w = 0;
+// --------------------------------------------------------------- Huffman ----
+// Canonical code from BITS/HUFFVAL (T.81 Annex C): a direct table for codes of up to kQuick bits,
+// and per-length first-code / first-index bounds (Figure F.16's MINCODE / VALPTR) for the rest.
+class HuffmanTable {
+public:
+	bool defined = false;
+	void build(const uint8_t counts[16], const uint8_t *symbols, int nsym) {
+		std::memset(quick_, 0xff, sizeof quick_);
+		std::memcpy(sym_, symbols, (size_t)nsym);
+		uint32_t code = 0;
+		int index = 0;
+		for (int len = 1; len <= 16; ++len) {
+			first_code_[len] = code;
+			first_index_[len] = index;
+			for (int k = 0; k < counts[len - 1]; ++k, ++index, ++code) {
+				if (code >= (1u << len)) throw Fail{"bad code lengths"};
+				if (len <= kQuick) {
+					const uint32_t lo = code << (kQuick - len), span = 1u << (kQuick - len);
+					for (uint32_t f = 0; f < span; ++f) quick_[lo + f] = (uint16_t)((len << 8) | symbols[index]);
+				}
+			}
+			end_code_[len] = code; // one past the last code of this length
+			code <<= 1;
+		}
+		defined = true;
+	}
+	inline int decode(BitSource &bits) const {
+		const uint32_t look = bits.peek(16);
+		const uint16_t q = quick_[look >> (16 - kQuick)];
+		if (q != 0xffff) {
+			bits.drop(q >> 8);
+			return q & 0xff;
+		}
+		for (int len = kQuick + 1; len <= 16; ++len) {
+			const uint32_t c = look >> (16 - len);
+			if (c < end_code_[len] && c >= first_code_[len]) {
+				bits.drop(len);
+				return sym_[first_index_[len] + (int)(c - first_code_[len])];
+			}
+		}
+		throw Fail{"bad huffman code"};
+	}
+
+private:
+	static constexpr int kQuick = 9;
+	uint16_t quick_[1 << kQuick];
+	uint8_t sym_[256];
+	uint32_t first_code_[17], end_code_[17];
+	int first_index_[17];
 };
 
-struct Decoder {
-	const uint8_t *p, *end;
-	std::string err;
-	Huffman huff_dc[4], huff_ac[4];
-	uint16_t dequant[4][64];
-	int img_x = 0, img_y = 0, img_n = 0;
-	int h_max = 1, v_max = 1, mcu_x = 0, mcu_y = 0;
-	Component comp[4];
-	uint32_t code_buffer = 0;
-	int code_bits = 0;
-	int marker = kMarkerNone;
-	bool nomore = false;
-	bool progressive = false;
-	int spec_start = 0, spec_end = 0, succ_high = 0, succ_low = 0, eob_run = 0;
-	bool jfif = false;
-	int app14 = -1, rgb = 0;
-	int scan_n = 0, order[4];
-	int restart_interval = 0, todo = 0;
+// T.81 F.2.2.1 EXTEND: the s-bit magnitude category value -> signed coefficient.
+inline int extend(uint32_t v, int s) { return s == 0 ? 0 : (v < (1u << (s - 1)) ? (int)v - (int)((1u << s) - 1) : (int)v); }
 
-	bool fail(const char *m) { if (err.empty()) err = m; return false; }
-	bool at_eof() const { return p >= end; }
-	int get8() { return p < end ? *p++ : 0; } // past the end reads as zeros, like stb's reader
-	int get16() { int a = get8(); return (a << 8) | get8(); }
-	void skip(int n) { if (n > 0) p = (end - p) < n ? end : p + n; }
+// ----------------------------------------------------------------- frame ----
+struct Plane {
+	int id = 0, hs = 1, vs = 1, tq = 0;
+	int width = 0, height = 0;           // samples of this component (ceil of the scaled frame size)
+	int blocks_w = 0, blocks_h = 0;      // 8x8 blocks covering width x height
+	int store_w = 0, store_h = 0;        // blocks in the coefficient store (padded to whole MCUs)
+	std::vector<int16_t> coef;           // store_w * store_h * 64, natural order, NOT dequantised
+	std::vector<uint8_t> samples;        // store_w*8 x store_h*8 after reconstruction
+	int dc_pred = 0;
+	int16_t *block(int bx, int by) { return &coef[((size_t)by * store_w + bx) * 64]; }
+};
 
-	// ---- entropy-coded segment bit reader (MSB first, 0xFF00 stuffing, markers stop it)
-	void grow() {
-		do {
-			unsigned b = nomore ? 0u : (unsigned)get8();
-			if (b == 0xff) {
-				int c = get8();
-				while (c == 0xff) c = get8();
-				if (c != 0) {
-					marker = c;
-					nomore = true;
+struct Scan {
+	int ncomp = 0;
+	int plane[4] = {0, 0, 0, 0};
+	int dc_table[4] = {0, 0, 0, 0}, ac_table[4] = {0, 0, 0, 0};
+	int ss = 0, se = 63, ah = 0, al = 0;
+};
+
+class JpegDecoder {
+public:
+	JpegDecoder(const uint8_t *data, size_t len) : d_(data), n_(len) {}
+
+	void decode(int req_comp, Image *out) {
+		parse();
+		reconstruct();
+		emit(req_comp, out);
+	}
+
+private:
+	const uint8_t *d_;
+	size_t n_, at_ = 0;
+	// tables
+	uint16_t quant_[4][64] = {}; // natural order
+	HuffmanTable dc_[4], ac_[4];
+	// frame
+	bool have_frame_ = false, progressive_ = false;
+	int width_ = 0, height_ = 0, ncomp_ = 0, hmax_ = 1, vmax_ = 1, mcus_w_ = 0, mcus_h_ = 0;
+	Plane planes_[4];
+	int restart_interval_ = 0;
+	bool jfif_ = false;
+	int adobe_transform_ = -1;
+	int rgb_ids_ = 0; // components whose ids spell 'R','G','B'
+	bool saw_scan_ = false;
+
+	// ---- byte access ----
+	uint8_t u8() {
+		if (at_ >= n_) throw Fail{"truncated"};
+		return d_[at_++];
+	}
+	int u16() {
+		const int hi = u8();
+		return (hi << 8) | u8();
+	}
+	// next marker code; fill bytes (0xff repeated) are allowed in front of it
+	int next_marker() {
+		if (u8() != 0xff) throw Fail{"expected marker"};
+		int m = u8();
+		while (m == 0xff) m = u8();
+		return m;
+	}
+
+	// ---- container ----
+	void parse() {
+		if (n_ < 4 || d_[0] != 0xff || d_[1] != 0xd8) throw Fail{"no SOI"};
+		at_ = 2;
+		for (;;) {
+			const int m = next_marker();
+			if (m == 0xd9) { // EOI
+				if (!have_frame_ || !saw_scan_) throw Fail{"no image data"};
+				return;
+			}
+			if (m == 0xda) {
+				scan_segment();
+				continue;
+			}
+			if (m == 0xc0 || m == 0xc1 || m == 0xc2) {
+				frame_segment(m == 0xc2);
+				continue;
+			}
+			if ((m >= 0xc3 && m <= 0xcf && m != 0xc4) || m == 0x01 || (m >= 0xd0 && m <= 0xd7) || m == 0x00)
+				throw Fail{m >= 0xc3 && m <= 0xcf ? "unsupported JPEG process (lossless / arithmetic / hierarchical)"
+				                                  : "unexpected marker"};
+			const int len = u16();
+			if (len < 2 || at_ + (size_t)(len - 2) > n_) throw Fail{"bad segment length"};
+			const size_t end = at_ + (size_t)(len - 2);
+			switch (m) {
+			case 0xdb: quant_segment(end); break;
+			case 0xc4: huffman_segment(end); break;
+			case 0xdd:
+				if (len != 4) throw Fail{"bad DRI length"};
+				restart_interval_ = u16();
+				break;
+			case 0xdc: { // DNL: only legal after the first scan, and must repeat the frame's height
+				if (len != 4) throw Fail{"bad DNL length"};
+				if (u16() != height_) throw Fail{"bad DNL height"};
+				break;
+			}
+			case 0xe0:
+				if (len >= 7 && std::memcmp(d_ + at_, "JFIF\0", 5) == 0) jfif_ = true;
+				break;
+			case 0xee:
+				if (len >= 14 && std::memcmp(d_ + at_, "Adobe\0", 6) == 0) adobe_transform_ = d_[at_ + 11];
+				break;
+			default:
+				if (!((m >= 0xe0 && m <= 0xef) || m == 0xfe)) throw Fail{"unknown marker"};
+			}
+			at_ = end;
+		}
+	}
+
+	void quant_segment(size_t end) {
+		while (at_ < end) {
+			const int pq_tq = u8();
+			const int precision = pq_tq >> 4, slot = pq_tq & 15;
+			if (precision > 1) throw Fail{"bad DQT precision"};
+			if (slot > 3) throw Fail{"bad DQT table"};
+			for (int k = 0; k < 64; ++k) quant_[slot][kNatural[k]] = (uint16_t)(precision ? u16() : u8());
+		}
+		if (at_ != end) throw Fail{"bad DQT length"};
+	}
+
+	void huffman_segment(size_t end) {
+		while (at_ < end) {
+			const int tc_th = u8();
+			const int cls = tc_th >> 4, slot = tc_th & 15;
+			if (cls > 1 || slot > 3) throw Fail{"bad DHT header"};
+			uint8_t counts[16];
+			int total = 0;
+			for (int k = 0; k < 16; ++k) total += counts[k] = u8();
+			if (total > 256) throw Fail{"bad DHT header"};
+			uint8_t symbols[256];
+			for (int k = 0; k < total; ++k) symbols[k] = u8();
+			(cls == 0 ? dc_ : ac_)[slot].build(counts, symbols, total);
+		}
+		if (at_ != end) throw Fail{"bad DHT length"};
+	}
+
+	void frame_segment(bool progressive) {
+		if (have_frame_) throw Fail{"multiple frames"};
+		const int len = u16();
+		if (len < 11) throw Fail{"bad SOF length"};
+		if (u8() != 8) throw Fail{"only 8-bit samples"};
+		height_ = u16();
+		width_ = u16();
+		if (height_ == 0) throw Fail{"no header height"}; // (height by DNL is refused, as the reference's loader does)
+		if (width_ == 0) throw Fail{"0 width"};
+		ncomp_ = u8();
+		if (ncomp_ != 1 && ncomp_ != 3 && ncomp_ != 4) throw Fail{"bad component count"};
+		if (len != 8 + 3 * ncomp_) throw Fail{"bad SOF length"};
+		if ((int64_t)width_ * height_ > ((int64_t)1 << 28)) throw Fail{"too large"};
+		static const char rgb[3] = {'R', 'G', 'B'};
+		for (int c = 0; c < ncomp_; ++c) {
+			Plane &p = planes_[c];
+			p.id = u8();
+			if (ncomp_ == 3 && p.id == rgb[c]) ++rgb_ids_;
+			const int hv = u8();
+			p.hs = hv >> 4;
+			p.vs = hv & 15;
+			if (p.hs < 1 || p.hs > 4 || p.vs < 1 || p.vs > 4) throw Fail{"bad sampling factor"};
+			p.tq = u8();
+			if (p.tq > 3) throw Fail{"bad quantisation table index"};
+			hmax_ = p.hs > hmax_ ? p.hs : hmax_;
+			vmax_ = p.vs > vmax_ ? p.vs : vmax_;
+		}
+		for (int c = 0; c < ncomp_; ++c) // (the upsampler below only scales by whole factors)
+			if (hmax_ % planes_[c].hs != 0 || vmax_ % planes_[c].vs != 0) throw Fail{"bad sampling factor"};
+		mcus_w_ = (width_ + 8 * hmax_ - 1) / (8 * hmax_);
+		mcus_h_ = (height_ + 8 * vmax_ - 1) / (8 * vmax_);
+		for (int c = 0; c < ncomp_; ++c) {
+			Plane &p = planes_[c];
+			p.width = (width_ * p.hs + hmax_ - 1) / hmax_;
+			p.height = (height_ * p.vs + vmax_ - 1) / vmax_;
+			p.blocks_w = (p.width + 7) / 8;
+			p.blocks_h = (p.height + 7) / 8;
+			p.store_w = mcus_w_ * p.hs;
+			p.store_h = mcus_h_ * p.vs;
+			p.coef.assign((size_t)p.store_w * p.store_h * 64, 0);
+		}
+		progressive_ = progressive;
+		have_frame_ = true;
+	}
+
+	// ---- scans ----
+	void scan_segment() {
+		if (!have_frame_) throw Fail{"scan before frame"};
+		const int len = u16();
+		Scan sc;
+		sc.ncomp = u8();
+		if (sc.ncomp < 1 || sc.ncomp > ncomp_) throw Fail{"bad SOS component count"};
+		if (len != 6 + 2 * sc.ncomp) throw Fail{"bad SOS length"};
+		for (int k = 0; k < sc.ncomp; ++k) {
+			const int id = u8(), tables = u8();
+			int which = -1;
+			for (int c = 0; c < ncomp_; ++c)
+				if (planes_[c].id == id) {
+					which = c;
+					break;
+				}
+			if (which < 0) throw Fail{"scan names an unknown component"};
+			sc.plane[k] = which;
+			sc.dc_table[k] = tables >> 4;
+			sc.ac_table[k] = tables & 15;
+			if (sc.dc_table[k] > 3 || sc.ac_table[k] > 3) throw Fail{"bad huffman table index"};
+		}
+		sc.ss = u8();
+		sc.se = u8();
+		const int a = u8();
+		sc.ah = a >> 4;
+		sc.al = a & 15;
+		if (progressive_) {
+			if (sc.ss > 63 || sc.se > 63 || sc.ss > sc.se || sc.ah > 13 || sc.al > 13) throw Fail{"bad SOS"};
+			if (sc.ss == 0 && sc.se != 0) throw Fail{"DC and AC in one progressive scan"};
+			if (sc.ss > 0 && sc.ncomp != 1) throw Fail{"interleaved AC scan"};
+		} else {
+			if (sc.ss != 0 || sc.ah != 0 || sc.al != 0) throw Fail{"bad SOS"};
+			sc.se = 63;
+		}
+
+		// The entropy-coded segment runs up to the next marker that is neither a stuffed 0xff00 nor a
+		// restart marker.  Un-stuff it once, remembering where each restart interval begins.
+		std::vector<uint8_t> bytes;
+		std::vector<size_t> starts(1, 0);
+		size_t i = at_;
+		for (; i < n_; ++i) {
+			const uint8_t b = d_[i];
+			if (b != 0xff) {
+				bytes.push_back(b);
+				continue;
+			}
+			if (i + 1 >= n_) { // a lone 0xff at the very end: nothing follows, the marker search below fails
+				i = n_;
+				break;
+			}
+			const uint8_t nxt = d_[i + 1];
+			if (nxt == 0x00) {
+				bytes.push_back(0xff);
+				++i;
+			} else if (nxt >= 0xd0 && nxt <= 0xd7) {
+				starts.push_back(bytes.size());
+				++i;
+			} else if (nxt == 0xff) {
+				continue; // fill byte in front of a marker
+			} else {
+				break; // a real marker: the segment ends in front of it
+			}
+		}
+		at_ = i;
+		starts.push_back(bytes.size());
+		run_scan(sc, bytes, starts);
+		saw_scan_ = true;
+	}
+
+	void run_scan(const Scan &sc, const std::vector<uint8_t> &bytes, const std::vector<size_t> &starts) {
+		for (int k = 0; k < sc.ncomp; ++k) {
+			const bool need_dc = sc.ss == 0 && sc.ah == 0, need_ac = sc.se > 0;
+			if (need_dc && !dc_[sc.dc_table[k]].defined) throw Fail{"missing DC huffman table"};
+			if (need_ac && !ac_[sc.ac_table[k]].defined) throw Fail{"missing AC huffman table"};
+		}
+		// units of the scan: MCUs when interleaved, the component's own blocks otherwise (T.81 A.2)
+		const bool interleaved = sc.ncomp > 1;
+		Plane &solo = planes_[sc.plane[0]];
+		const int units_w = interleaved ? mcus_w_ : solo.blocks_w, units_h = interleaved ? mcus_h_ : solo.blocks_h;
+		const int64_t total = (int64_t)units_w * units_h;
+		const int64_t per_interval = restart_interval_ > 0 ? restart_interval_ : total;
+		int64_t unit = 0;
+		for (size_t iv = 0; iv + 1 < starts.size() && unit < total; ++iv) {
+			BitSource bits(bytes.data() + starts[iv], starts[iv + 1] - starts[iv]);
+			for (int c = 0; c < ncomp_; ++c) planes_[c].dc_pred = 0;
+			int eob_run = 0;
+			for (int64_t k = 0; k < per_interval && unit < total; ++k, ++unit) {
+				const int ux = (int)(unit % units_w), uy = (int)(unit / units_w);
+				if (!interleaved) {
+					one_block(sc, 0, solo.block(ux, uy), bits, eob_run);
+					continue;
+				}
+				for (int s = 0; s < sc.ncomp; ++s) {
+					Plane &p = planes_[sc.plane[s]];
+					for (int by = 0; by < p.vs; ++by)
+						for (int bx = 0; bx < p.hs; ++bx) one_block(sc, s, p.block(ux * p.hs + bx, uy * p.vs + by), bits, eob_run);
+				}
+			}
+		}
+		// (fewer intervals than the frame needs: the blocks not reached keep their zero coefficients)
+	}
+
+	void one_block(const Scan &sc, int s, int16_t *blk, BitSource &bits, int &eob_run) {
+		Plane &p = planes_[sc.plane[s]];
+		if (!progressive_) {
+			sequential_block(p, dc_[sc.dc_table[s]], ac_[sc.ac_table[s]], blk, bits);
+		} else if (sc.ss == 0) {
+			if (sc.ah == 0) {
+				const int t = dc_[sc.dc_table[s]].decode(bits);
+				if (t > 15) throw Fail{"bad huffman code"};
+				p.dc_pred += extend(bits.take(t), t);
+				blk[0] = (int16_t)(p.dc_pred * (1 << sc.al)); // (wraps like a 16-bit store on damaged streams)
+			} else if (bits.take(1)) {
+				blk[0] = (int16_t)(blk[0] + (1 << sc.al));
+			}
+		} else if (sc.ah == 0) {
+			ac_first(sc, ac_[sc.ac_table[s]], blk, bits, eob_run);
+		} else {
+			ac_refine(sc, ac_[sc.ac_table[s]], blk, bits, eob_run);
+		}
+	}
+
+	// T.81 F.2.2: DC difference, then run/size pairs up to EOB.
+	void sequential_block(Plane &p, const HuffmanTable &dc, const HuffmanTable &ac, int16_t *blk, BitSource &bits) {
+		const int t = dc.decode(bits);
+		if (t > 15) throw Fail{"bad huffman code"};
+		p.dc_pred += extend(bits.take(t), t);
+		blk[0] = (int16_t)p.dc_pred;
+		for (int k = 1; k < 64;) {
+			const int rs = ac.decode(bits), run = rs >> 4, size = rs & 15;
+			if (size == 0) {
+				if (run != 15) break; // EOB
+				k += 16;              // ZRL
+				continue;
+			}
+			k += run;
+			// (a run past the block's end is a damaged stream: the value lands on the last coefficient)
+			blk[k < 64 ? kNatural[k] : 63] = (int16_t)extend(bits.take(size), size);
+			++k;
+		}
+	}
+
+	// T.81 G.1.2.2: first pass over a spectral band, with end-of-band runs.
+	void ac_first(const Scan &sc, const HuffmanTable &ac, int16_t *blk, BitSource &bits, int &eob_run) {
+		if (eob_run > 0) {
+			--eob_run;
+			return;
+		}
+		for (int k = sc.ss; k <= sc.se;) {
+			const int rs = ac.decode(bits), run = rs >> 4, size = rs & 15;
+			if (size == 0) {
+				if (run < 15) { // EOBn: this block and 2^run - 1 + extra more end here
+					eob_run = (1 << run) - 1;
+					if (run) eob_run += (int)bits.take(run);
 					return;
 				}
+				k += 16;
+				continue;
 			}
-			const int sh = 24 - code_bits; // > 31 only after a corrupt stream drove code_bits negative
-			if (sh < 32) code_buffer |= b << sh;
-			code_bits += 8;
-		} while (code_bits <= 24);
-	}
-	int huff_decode(const Huffman &h) {
-		if (code_bits < 16) grow();
-		const uint32_t temp = code_buffer >> 16;
-		int k;
-		for (k = 1; k < 17; ++k) // (a table that was never defined has maxcode all zero: k runs to 17)
-			if (temp < h.maxcode[k]) break;
-		if (k == 17) { code_bits -= 16; return -1; }
-		if (k > code_bits) return -1;
-		const int c = (int)((code_buffer >> (32 - k)) & ((1u << k) - 1)) + h.delta[k];
-		if (c < 0 || c > 255) return -1;
-		code_bits -= k;
-		code_buffer <<= k;
-		return h.values[c];
-	}
-	static uint32_t rotl(uint32_t v, int n) { n &= 31; return n ? (v << n) | (v >> (32 - n)) : v; }
-	int extend_receive(int n) { // JPEG RECEIVE + EXTEND
-		if (code_bits < n) grow();
-		const int sgn = (int)(code_buffer >> 31);
-		uint32_t k = rotl(code_buffer, n);
-		const uint32_t mask = (1u << n) - 1;
-		code_buffer = k & ~mask;
-		k &= mask;
-		code_bits -= n;
-		const int bias = -(1 << n) + 1;
-		return (int)k + (sgn ? 0 : bias);
-	}
-	int get_bits(int n) {
-		if (code_bits < n) grow();
-		uint32_t k = rotl(code_buffer, n);
-		const uint32_t mask = (1u << n) - 1;
-		code_buffer = k & ~mask;
-		k &= mask;
-		code_bits -= n;
-		return (int)k;
-	}
-	bool get_bit() {
-		if (code_bits < 1) grow();
-		const uint32_t k = code_buffer;
-		code_buffer <<= 1;
-		--code_bits;
-		return (k & 0x80000000u) != 0;
+			k += run;
+			blk[k < 64 ? kNatural[k] : 63] = (int16_t)(extend(bits.take(size), size) * (1 << sc.al));
+			++k;
+		}
 	}
 
-	// ---- block decoders
-	bool decode_block(int16_t data[64], const Huffman &hdc, const Huffman &hac, int b, const uint16_t *dq) {
-		if (code_bits < 16) grow();
-		const int t = huff_decode(hdc);
-		if (t < 0 || t > 15) return fail("bad huffman code");
-		memset(data, 0, 64 * sizeof(int16_t));
-		const int diff = t ? extend_receive(t) : 0;
-		const int dc = comp[b].dc_pred + diff;
-		comp[b].dc_pred = dc;
-		data[0] = (int16_t)(dc * dq[0]);
-		int k = 1;
-		do {
-			const int rs = huff_decode(hac);
-			if (rs < 0) return fail("bad huffman code");
-			const int s = rs & 15, r = rs >> 4;
-			if (s == 0) {
-				if (rs != 0xf0) break;
-				k += 16;
-			} else {
-				k += r;
-				const int zig = kDezigzag[k++];
-				data[zig] = (int16_t)(extend_receive(s) * dq[zig]);
-			}
-		} while (k < 64);
-		return true;
-	}
-	bool decode_block_prog_dc(int16_t data[64], const Huffman &hdc, int b) {
-		if (spec_end != 0) return fail("can't merge dc and ac");
-		if (code_bits < 16) grow();
-		if (succ_high == 0) {
-			memset(data, 0, 64 * sizeof(int16_t));
-			const int t = huff_decode(hdc);
-			if (t < 0 || t > 15) return fail("can't merge dc and ac");
-			const int diff = t ? extend_receive(t) : 0;
-			const int dc = comp[b].dc_pred + diff;
-			comp[b].dc_pred = dc;
-			data[0] = (int16_t)(dc * (1 << succ_low));
-		} else if (get_bit()) {
-			data[0] = (int16_t)(data[0] + (int16_t)(1 << succ_low));
-		}
-		return true;
-	}
-	bool decode_block_prog_ac(int16_t data[64], const Huffman &hac) {
-		if (spec_start == 0) return fail("can't merge dc and ac");
-		if (succ_high == 0) {
-			const int shift = succ_low;
-			if (eob_run) { --eob_run; return true; }
-			int k = spec_start;
-			do {
-				const int rs = huff_decode(hac);
-				if (rs < 0) return fail("bad huffman code");
-				const int s = rs & 15, r = rs >> 4;
-				if (s == 0) {
-					if (r < 15) {
-						eob_run = 1 << r;
-						if (r) eob_run += get_bits(r);
-						--eob_run;
+	// T.81 G.1.2.3: refinement of a band -- one correction bit for every coefficient that is already
+	// non-zero, new +-1 coefficients placed after `run` still-zero positions.
+	void ac_refine(const Scan &sc, const HuffmanTable &ac, int16_t *blk, BitSource &bits, int &eob_run) {
+		const int plus = 1 << sc.al, minus = -plus;
+		auto correct = [&](int16_t &c) {
+			if (bits.take(1) && (c & plus) == 0) c = (int16_t)(c + (c > 0 ? plus : minus));
+		};
+		int k = sc.ss;
+		if (eob_run == 0) {
+			while (k <= sc.se) {
+				const int rs = ac.decode(bits), size = rs & 15;
+				int run = rs >> 4, value = 0;
+				if (size == 0) {
+					if (run < 15) {
+						eob_run = (1 << run) - 1;
+						if (run) eob_run += (int)bits.take(run);
+						++eob_run; // (counts this block too: handled by the tail below)
 						break;
 					}
-					k += 16;
+					// ZRL: 16 zero positions, i.e. run = 15 and a zero "new" coefficient
 				} else {
-					k += r;
-					const int zig = kDezigzag[k++];
-					data[zig] = (int16_t)(extend_receive(s) * (1 << shift));
+					if (size != 1) throw Fail{"bad huffman code"};
+					value = bits.take(1) ? plus : minus;
 				}
-			} while (k <= spec_end);
-		} else {
-			const int16_t bit = (int16_t)(1 << succ_low);
-			auto refine = [&](int16_t *q) {
-				if (get_bit() && (*q & bit) == 0) *q = (int16_t)(*q > 0 ? *q + bit : *q - bit);
-			};
-			if (eob_run) {
-				--eob_run;
-				for (int k = spec_start; k <= spec_end; ++k) {
-					int16_t *q = &data[kDezigzag[k]];
-					if (*q != 0) refine(q);
-				}
-			} else {
-				int k = spec_start;
-				do {
-					const int rs = huff_decode(hac);
-					if (rs < 0) return fail("bad huffman code");
-					int s = rs & 15, r = rs >> 4;
-					if (s == 0) {
-						if (r < 15) {
-							eob_run = (1 << r) - 1;
-							if (r) eob_run += get_bits(r);
-							r = 64; // force end of block
-						}
+				while (k <= sc.se) {
+					int16_t &c = blk[kNatural[k++]];
+					if (c != 0) {
+						correct(c);
+					} else if (run == 0) {
+						c = (int16_t)value;
+						break;
 					} else {
-						if (s != 1) return fail("bad huffman code");
-						s = get_bit() ? bit : -bit;
+						--run;
 					}
-					while (k <= spec_end) {
-						int16_t *q = &data[kDezigzag[k++]];
-						if (*q != 0) {
-							refine(q);
-						} else {
-							if (r == 0) { *q = (int16_t)s; break; }
-							--r;
-						}
-					}
-				} while (k <= spec_end);
+				}
 			}
 		}
-		return true;
+		if (eob_run > 0) {
+			for (; k <= sc.se; ++k) {
+				int16_t &c = blk[kNatural[k]];
+				if (c != 0) correct(c);
+			}
+			--eob_run;
+		}
 	}
 
-	// ---- inverse DCT (integer, 12 fractional bits)
-	static inline uint8_t clamp255(int x) { return (unsigned)x > 255u ? (x < 0 ? 0 : 255) : (uint8_t)x; }
-	static void idct_block(uint8_t *out, int stride, const int16_t d[64]) {
-#define HMRM_F2F(x) ((int)(((x) * 4096 + 0.5)))
-#define HMRM_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                       \
-	int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                 \
-	p2 = s2; p3 = s6;                                                                        \
-	p1 = (p2 + p3) * HMRM_F2F(0.5411961f);                                                   \
-	t2 = p1 + p3 * HMRM_F2F(-1.847759065f);                                                  \
-	t3 = p1 + p2 * HMRM_F2F(0.765366865f);                                                   \
-	p2 = s0; p3 = s4;                                                                        \
-	t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                            \
-	x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                  \
-	t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                      \
-	p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                                  \
-	p5 = (p3 + p4) * HMRM_F2F(1.175875602f);                                                 \
-	t0 = t0 * HMRM_F2F(0.298631336f); t1 = t1 * HMRM_F2F(2.053119869f);                      \
-	t2 = t2 * HMRM_F2F(3.072711026f); t3 = t3 * HMRM_F2F(1.501321110f);                      \
-	p1 = p5 + p1 * HMRM_F2F(-0.899976223f); p2 = p5 + p2 * HMRM_F2F(-2.562915447f);          \
-	p3 = p3 * HMRM_F2F(-1.961570560f); p4 = p4 * HMRM_F2F(-0.390180644f);                    \
-	t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
-		int val[64];
-		for (int i = 0; i < 8; ++i) {
-			const int16_t *c = d + i;
-			int *v = val + i;
-			if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
-				const int dcterm = c[0] * 4;
-				v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
-			} else {
-				HMRM_IDCT_1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56])
-				x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-				v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
-				v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
-				v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
-				v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+	// ---- reconstruction ----
+	// PIXEL CONTRACT (stb_image v2.27): the 8x8 inverse DCT in 32-bit fixed point -- an even/odd
+	// factorisation with 12-bit constants, columns first keeping two extra bits (>> 10 after + 512),
+	// then rows (>> 17 after + 65536 + (128 << 17), i.e. rounding and the +128 level shift), clamped to
+	// 0..255; a column whose AC terms are all zero is just its DC term * 4.  The constants are computed
+	// the way that decoder spells them, (int)(c * 4096 + 0.5) on a float literal: negative ones
+	// therefore round towards zero.
+	static constexpr int fix(float c) { return (int)(c * 4096 + 0.5); }
+	struct Odd {
+		int a, b, c, d;
+	};
+	static inline void even_part(int s0, int s2, int s4, int s6, int e[4]) {
+		const int z = (s2 + s6) * fix(0.5411961f);
+		const int lo = z + s6 * fix(-1.847759065f), hi = z + s2 * fix(0.765366865f);
+		const int sum = (s0 + s4) * 4096, diff = (s0 - s4) * 4096;
+		e[0] = sum + hi;
+		e[3] = sum - hi;
+		e[1] = diff + lo;
+		e[2] = diff - lo;
+	}
+	static inline Odd odd_part(int s1, int s3, int s5, int s7) {
+		const int p3 = s7 + s3, p4 = s5 + s1, p1 = s7 + s1, p2 = s5 + s3;
+		const int p5 = (p3 + p4) * fix(1.175875602f);
+		const int q1 = p5 + p1 * fix(-0.899976223f), q2 = p5 + p2 * fix(-2.562915447f);
+		const int q3 = p3 * fix(-1.961570560f), q4 = p4 * fix(-0.390180644f);
+		Odd o;
+		o.a = s7 * fix(0.298631336f) + q1 + q3;
+		o.b = s5 * fix(2.053119869f) + q2 + q4;
+		o.c = s3 * fix(3.072711026f) + q2 + q3;
+		o.d = s1 * fix(1.501321110f) + q1 + q4;
+		return o;
+	}
+	static inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+	static void idct8x8(const int16_t *in, const uint16_t *q, uint8_t *out, int stride) {
+		int d[64], mid[64];
+		for (int i = 0; i < 64; ++i) d[i] = (int16_t)(in[i] * q[i]); // dequantised coefficient as a 16-bit value
+		for (int x = 0; x < 8; ++x) {
+			const int *c = d + x;
+			int *m = mid + x;
+			if (!(c[8] | c[16] | c[24] | c[32] | c[40] | c[48] | c[56])) {
+				const int dc = c[0] * 4;
+				for (int y = 0; y < 8; ++y) m[8 * y] = dc;
+				continue;
 			}
+			int e[4];
+			even_part(c[0], c[16], c[32], c[48], e);
+			const Odd o = odd_part(c[8], c[24], c[40], c[56]);
+			for (int k = 0; k < 4; ++k) e[k] += 512;
+			m[0] = (e[0] + o.d) >> 10;
+			m[56] = (e[0] - o.d) >> 10;
+			m[8] = (e[1] + o.c) >> 10;
+			m[48] = (e[1] - o.c) >> 10;
+			m[16] = (e[2] + o.b) >> 10;
+			m[40] = (e[2] - o.b) >> 10;
+			m[24] = (e[3] + o.a) >> 10;
+			m[32] = (e[3] - o.a) >> 10;
 		}
-		for (int i = 0; i < 8; ++i) {
-			const int *v = val + i * 8;
-			uint8_t *o = out + (size_t)i * stride;
-			HMRM_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-			x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17);
-			x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
-			o[0] = clamp255((x0 + t3) >> 17); o[7] = clamp255((x0 - t3) >> 17);
-			o[1] = clamp255((x1 + t2) >> 17); o[6] = clamp255((x1 - t2) >> 17);
-			o[2] = clamp255((x2 + t1) >> 17); o[5] = clamp255((x2 - t1) >> 17);
-			o[3] = clamp255((x3 + t0) >> 17); o[4] = clamp255((x3 - t0) >> 17);
+		for (int y = 0; y < 8; ++y) {
+			const int *r = mid + 8 * y;
+			uint8_t *o8 = out + (size_t)y * stride;
+			int e[4];
+			even_part(r[0], r[2], r[4], r[6], e);
+			const Odd o = odd_part(r[1], r[3], r[5], r[7]);
+			for (int k = 0; k < 4; ++k) e[k] += 65536 + (128 << 17);
+			o8[0] = clamp8((e[0] + o.d) >> 17);
+			o8[7] = clamp8((e[0] - o.d) >> 17);
+			o8[1] = clamp8((e[1] + o.c) >> 17);
+			o8[6] = clamp8((e[1] - o.c) >> 17);
+			o8[2] = clamp8((e[2] + o.b) >> 17);
+			o8[5] = clamp8((e[2] - o.b) >> 17);
+			o8[3] = clamp8((e[3] + o.a) >> 17);
+			o8[4] = clamp8((e[3] - o.a) >> 17);
 		}
-#undef HMRM_IDCT_1D
-#undef HMRM_F2F
 	}
 
-	// ---- markers and headers
-	int get_marker() {
-		if (marker != kMarkerNone) { int x = marker; marker = kMarkerNone; return x; }
-		int x = get8();
-		if (x != 0xff) return kMarkerNone;
-		while (x == 0xff) x = get8();
-		return x;
+	void reconstruct() {
+		for (int c = 0; c < ncomp_; ++c) {
+			Plane &p = planes_[c];
+			const int stride = p.store_w * 8;
+			p.samples.assign((size_t)stride * p.store_h * 8, 0);
+			for (int by = 0; by < p.store_h; ++by)
+				for (int bx = 0; bx < p.store_w; ++bx)
+					idct8x8(p.block(bx, by), quant_[p.tq], &p.samples[(size_t)by * 8 * stride + (size_t)bx * 8], stride);
+		}
 	}
-	void reset_entropy() {
-		code_bits = 0;
-		code_buffer = 0;
-		nomore = false;
-		for (auto &c : comp) c.dc_pred = 0;
-		marker = kMarkerNone;
-		todo = restart_interval ? restart_interval : 0x7fffffff;
-		eob_run = 0;
-	}
-	bool process_marker(int m) {
-		switch (m) {
-		case kMarkerNone: return fail("expected marker");
-		case 0xDD:
-			if (get16() != 4) return fail("bad DRI len");
-			restart_interval = get16();
-			return true;
-		case 0xDB: {
-			int L = get16() - 2;
-			while (L > 0) {
-				const int q = get8(), prec = q >> 4, t = q & 15;
-				if (prec != 0 && prec != 1) return fail("bad DQT type");
-				if (t > 3) return fail("bad DQT table");
-				for (int i = 0; i < 64; ++i) dequant[t][kDezigzag[i]] = (uint16_t)(prec ? get16() : get8());
-				L -= prec ? 129 : 65;
+
+	// PIXEL CONTRACT (stb_image v2.27): chroma upsampling.  Factor 2 uses the "triangle" filter -- each
+	// output sample is 3/4 of the nearest input sample and 1/4 of the next nearest, in both directions
+	// for 2x2 (then with 4 fractional bits: (3a + b + 8) >> 4), with +2 >> 2 rounding in one direction;
+	// the first and last output of a row copy the edge sample (2x1) or use only the vertical blend
+	// (2x2).  Other factors repeat samples.  Vertically the next-nearest row is the one above for even
+	// output rows and the one below for odd ones, clamped to the component's own rows.
+	void upsample_row(const Plane &p, int row, std::vector<uint8_t> &line, std::vector<uint8_t> &scratch) const {
+		const int hx = hmax_ / p.hs, vx = vmax_ / p.vs;
+		const int stride = p.store_w * 8;
+		const int w = (width_ + hx - 1) / hx; // input samples that contribute to the visible row
+		const int near_row = row / vx;
+		const uint8_t *a = &p.samples[(size_t)near_row * stride];
+		line.resize((size_t)w * hx + 8);
+		if (hx == 1 && vx == 1) {
+			std::memcpy(line.data(), a, (size_t)w);
+			return;
+		}
+		int far_row = near_row;
+		if (vx == 2) {
+			far_row = (row & 1) ? near_row + 1 : near_row - 1;
+			if (far_row < 0) far_row = 0;
+			if (far_row > p.height - 1) far_row = p.height - 1;
+		}
+		const uint8_t *b = &p.samples[(size_t)far_row * stride];
+		if (hx == 1 && vx == 2) {
+			for (int i = 0; i < w; ++i) line[(size_t)i] = (uint8_t)((3 * a[i] + b[i] + 2) >> 2);
+		} else if (hx == 2 && vx == 1) {
+			if (w == 1) {
+				line[0] = line[1] = a[0];
+				return;
 			}
-			return L == 0 ? true : fail("bad DQT len");
-		}
-		case 0xC4: {
-			int L = get16() - 2;
-			while (L > 0) {
-				int sizes[16], n = 0;
-				const int q = get8(), tc = q >> 4, th = q & 15;
-				if (tc > 1 || th > 3) return fail("bad DHT header");
-				for (int i = 0; i < 16; ++i) { sizes[i] = get8(); n += sizes[i]; }
-				if (n > 256) return fail("bad DHT header");
-				L -= 17;
-				Huffman &h = tc == 0 ? huff_dc[th] : huff_ac[th];
-				if (!h.build(sizes)) return fail("bad code lengths");
-				for (int i = 0; i < n; ++i) h.values[i] = (uint8_t)get8();
-				L -= n;
+			line[0] = a[0];
+			line[1] = (uint8_t)((a[0] * 3 + a[1] + 2) >> 2);
+			for (int i = 1; i < w - 1; ++i) {
+				const int n = 3 * a[i] + 2;
+				line[(size_t)2 * i] = (uint8_t)((n + a[i - 1]) >> 2);
+				line[(size_t)2 * i + 1] = (uint8_t)((n + a[i + 1]) >> 2);
 			}
-			return L == 0 ? true : fail("bad DHT len");
-		}
-		default: break;
-		}
-		if ((m >= 0xE0 && m <= 0xEF) || m == 0xFE) {
-			int L = get16();
-			if (L < 2) return fail(m == 0xFE ? "bad COM len" : "bad APP len");
-			L -= 2;
-			if (m == 0xE0 && L >= 5) {
-				static const uint8_t tag[5] = {'J', 'F', 'I', 'F', 0};
-				bool ok = true;
-				for (int i = 0; i < 5; ++i) if (get8() != tag[i]) ok = false;
-				L -= 5;
-				if (ok) jfif = true;
-			} else if (m == 0xEE && L >= 12) {
-				static const uint8_t tag[6] = {'A', 'd', 'o', 'b', 'e', 0};
-				bool ok = true;
-				for (int i = 0; i < 6; ++i) if (get8() != tag[i]) ok = false;
-				L -= 6;
-				if (ok) {
-					get8(); get16(); get16();
-					app14 = get8();
-					L -= 6;
-				}
+			// (pixel contract: this one sample weighs its LEFT neighbour 3/4, unlike every other one)
+			line[(size_t)2 * w - 2] = (uint8_t)((3 * a[w - 2] + a[w - 1] + 2) >> 2);
+			line[(size_t)2 * w - 1] = a[w - 1];
+		} else if (hx == 2 && vx == 2) {
+			if (w == 1) {
+				line[0] = line[1] = (uint8_t)((3 * a[0] + b[0] + 2) >> 2);
+				return;
 			}
-			skip(L);
-			return true;
-		}
-		return fail("unknown marker");
-	}
-	bool process_frame_header() {
-		const int Lf = get16();
-		if (Lf < 11) return fail("bad SOF len");
-		if (get8() != 8) return fail("only 8-bit");
-		img_y = get16();
-		if (img_y == 0) return fail("no header height");
-		img_x = get16();
-		if (img_x == 0) return fail("0 width");
-		const int c = get8();
-		if (c != 3 && c != 1 && c != 4) return fail("bad component count");
-		img_n = c;
-		if (Lf != 8 + 3 * img_n) return fail("bad SOF len");
-		rgb = 0;
-		for (int i = 0; i < img_n; ++i) {
-			static const uint8_t rgb_ids[3] = {'R', 'G', 'B'};
-			comp[i].id = get8();
-			if (img_n == 3 && comp[i].id == rgb_ids[i]) ++rgb;
-			const int q = get8();
-			comp[i].h = q >> 4;
-			comp[i].v = q & 15;
-			if (!comp[i].h || comp[i].h > 4) return fail("bad H");
-			if (!comp[i].v || comp[i].v > 4) return fail("bad V");
-			comp[i].tq = get8();
-			if (comp[i].tq > 3) return fail("bad TQ");
-		}
-		if ((int64_t)img_x * img_y * img_n > ((int64_t)1 << 30)) return fail("too large");
-		h_max = v_max = 1;
-		for (int i = 0; i < img_n; ++i) {
-			if (comp[i].h > h_max) h_max = comp[i].h;
-			if (comp[i].v > v_max) v_max = comp[i].v;
-		}
-		for (int i = 0; i < img_n; ++i) {
-			if (h_max % comp[i].h != 0) return fail("bad H");
-			if (v_max % comp[i].v != 0) return fail("bad V");
-		}
-		const int mcu_w = h_max * 8, mcu_h = v_max * 8;
-		mcu_x = (img_x + mcu_w - 1) / mcu_w;
-		mcu_y = (img_y + mcu_h - 1) / mcu_h;
-		for (int i = 0; i < img_n; ++i) {
-			Component &k = comp[i];
-			k.x = (img_x * k.h + h_max - 1) / h_max;
-			k.y = (img_y * k.v + v_max - 1) / v_max;
-			k.w2 = mcu_x * k.h * 8;
-			k.h2 = mcu_y * k.v * 8;
-			k.data.assign((size_t)k.w2 * k.h2, 0);
-			if (progressive) {
-				k.coeff_w = k.w2 / 8;
-				k.coeff.assign((size_t)k.w2 * k.h2, 0);
+			int prev = 3 * a[0] + b[0];
+			line[0] = (uint8_t)((prev + 2) >> 2);
+			for (int i = 1; i < w; ++i) {
+				const int cur = 3 * a[i] + b[i];
+				line[(size_t)2 * i - 1] = (uint8_t)((3 * prev + cur + 8) >> 4);
+				line[(size_t)2 * i] = (uint8_t)((3 * cur + prev + 8) >> 4);
+				prev = cur;
 			}
-		}
-		return true;
-	}
-	bool decode_header() {
-		jfif = false;
-		app14 = -1;
-		marker = kMarkerNone;
-		int m = get_marker();
-		if (m != 0xd8) return fail("no SOI");
-		m = get_marker();
-		while (!(m == 0xc0 || m == 0xc1 || m == 0xc2)) {
-			if (!process_marker(m)) return false;
-			m = get_marker();
-			while (m == kMarkerNone) {
-				if (at_eof()) return fail("no SOF");
-				m = get_marker();
-			}
-		}
-		progressive = (m == 0xc2);
-		return process_frame_header();
-	}
-	bool process_scan_header() {
-		const int Ls = get16();
-		scan_n = get8();
-		if (scan_n < 1 || scan_n > 4 || scan_n > img_n) return fail("bad SOS component count");
-		if (Ls != 6 + 2 * scan_n) return fail("bad SOS len");
-		for (int i = 0; i < scan_n; ++i) {
-			const int id = get8(), q = get8();
-			int which = 0;
-			for (; which < img_n; ++which) if (comp[which].id == id) break;
-			if (which == img_n) return fail("bad SOS component");
-			comp[which].hd = q >> 4;
-			comp[which].ha = q & 15;
-			if (comp[which].hd > 3) return fail("bad DC huff");
-			if (comp[which].ha > 3) return fail("bad AC huff");
-			order[i] = which;
-		}
-		spec_start = get8();
-		spec_end = get8();
-		const int aa = get8();
-		succ_high = aa >> 4;
-		succ_low = aa & 15;
-		if (progressive) {
-			if (spec_start > 63 || spec_end > 63 || spec_start > spec_end || succ_high > 13 || succ_low > 13)
-				return fail("bad SOS");
+			line[(size_t)2 * w - 1] = (uint8_t)((prev + 2) >> 2);
 		} else {
-			if (spec_start != 0 || succ_high != 0 || succ_low != 0) return fail("bad SOS");
-			spec_end = 63;
+			// any other whole factor: each sample of the nearest row repeated hx times
+			for (int i = 0; i < w; ++i)
+				for (int k = 0; k < hx; ++k) line[(size_t)i * hx + k] = a[i];
 		}
-		return true;
+		(void)scratch;
 	}
-	// returns false on hard error; *stop set when a non-restart marker ends the scan early
-	bool restart_check(bool *stop) {
-		if (--todo <= 0) {
-			if (code_bits < 24) grow();
-			if (!(marker >= 0xd0 && marker <= 0xd7)) { *stop = true; return true; }
-			reset_entropy();
-		}
-		return true;
+
+	// PIXEL CONTRACT (stb_image v2.27): YCbCr -> RGB with 20 fractional bits; coefficients are
+	// round(c * 4096) << 8, luma carries the rounding half, and the Cb term of green is masked to its
+	// upper 16 bits before the sum.
+	static constexpr int cfix(float c) { return ((int)(c * 4096.0f + 0.5f)) << 8; }
+	static inline void ycc_to_rgb(int y, int cb, int cr, uint8_t *rgb) {
+		const int yf = (y << 20) + (1 << 19);
+		cb -= 128;
+		cr -= 128;
+		const int r = yf + cr * cfix(1.40200f);
+		const int g = yf + cr * -cfix(0.71414f) + (int)((unsigned)(cb * -cfix(0.34414f)) & 0xffff0000u);
+		const int b = yf + cb * cfix(1.77200f);
+		rgb[0] = clamp8(r >> 20);
+		rgb[1] = clamp8(g >> 20);
+		rgb[2] = clamp8(b >> 20);
 	}
-	bool parse_entropy_coded_data() {
-		reset_entropy();
-		bool stop = false;
-		int16_t block[64];
-		if (scan_n == 1) {
-			const int n = order[0];
-			Component &c = comp[n];
-			const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
-			for (int j = 0; j < h; ++j)
-				for (int i = 0; i < w; ++i) {
-					if (!progressive) {
-						if (!decode_block(block, huff_dc[c.hd], huff_ac[c.ha], n, dequant[c.tq])) return false;
-						idct_block(&c.data[(size_t)c.w2 * j * 8 + i * 8], c.w2, block);
+	// PIXEL CONTRACT (stb_image v2.27): x*y/255 as (t + (t >> 8)) >> 8 with t = x*y + 128 (CMYK / YCCK);
+	// luma of an RGB triple as (77 r + 150 g + 29 b) >> 8.
+	static inline uint8_t mul255(int x, int y) {
+		const unsigned t = (unsigned)(x * y + 128);
+		return (uint8_t)((t + (t >> 8)) >> 8);
+	}
+	static inline uint8_t luma(int r, int g, int b) { return (uint8_t)((r * 77 + g * 150 + b * 29) >> 8); }
+
+	void emit(int req_comp, Image *out) {
+		const int n = req_comp ? req_comp : (ncomp_ >= 3 ? 3 : 1);
+		const bool is_rgb = ncomp_ == 3 && (rgb_ids_ == 3 || (adobe_transform_ == 0 && !jfif_));
+		// grey output of a YCbCr file needs the luma plane only
+		const int used = (ncomp_ == 3 && n < 3 && !is_rgb) ? 1 : ncomp_;
+		out->w = width_;
+		out->h = height_;
+		out->comp = n;
+		out->comp_in_file = ncomp_ >= 3 ? 3 : 1;
+		out->px.assign((size_t)width_ * height_ * n, 0);
+		std::vector<uint8_t> line[4], scratch;
+		for (int y = 0; y < height_; ++y) {
+			for (int c = 0; c < used; ++c) upsample_row(planes_[c], y, line[c], scratch);
+			uint8_t *o = &out->px[(size_t)y * width_ * n];
+			const uint8_t *c0 = line[0].data(), *c1 = line[1].data(), *c2 = line[2].data(), *c3 = line[3].data();
+			for (int x = 0; x < width_; ++x, o += n) {
+				uint8_t rgb[3];
+				if (ncomp_ == 1 || used == 1) {
+					rgb[0] = rgb[1] = rgb[2] = c0[x];
+					if (n < 3) {
+						o[0] = c0[x];
+						if (n == 2) o[1] = 255;
+						continue;
+					}
+				} else if (ncomp_ == 3) {
+					if (is_rgb) {
+						rgb[0] = c0[x];
+						rgb[1] = c1[x];
+						rgb[2] = c2[x];
 					} else {
-						int16_t *data = &c.coeff[64 * ((size_t)i + (size_t)j * c.coeff_w)];
-						if (spec_start == 0) {
-							if (!decode_block_prog_dc(data, huff_dc[c.hd], n)) return false;
-						} else if (!decode_block_prog_ac(data, huff_ac[c.ha])) return false;
+						ycc_to_rgb(c0[x], c1[x], c2[x], rgb);
 					}
-					if (!restart_check(&stop)) return false;
-					if (stop) return true;
-				}
-			return true;
-		}
-		for (int j = 0; j < mcu_y; ++j)
-			for (int i = 0; i < mcu_x; ++i) {
-				for (int k = 0; k < scan_n; ++k) {
-					const int n = order[k];
-					Component &c = comp[n];
-					for (int y = 0; y < c.v; ++y)
-						for (int x = 0; x < c.h; ++x) {
-							const int bx = i * c.h + x, by = j * c.v + y;
-							if (!progressive) {
-								if (!decode_block(block, huff_dc[c.hd], huff_ac[c.ha], n, dequant[c.tq])) return false;
-								idct_block(&c.data[(size_t)c.w2 * by * 8 + bx * 8], c.w2, block);
-							} else {
-								int16_t *data = &c.coeff[64 * ((size_t)bx + (size_t)by * c.coeff_w)];
-								if (!decode_block_prog_dc(data, huff_dc[c.hd], n)) return false;
-							}
+				} else { // four components
+					const int k = c3[x];
+					if (adobe_transform_ == 0) { // CMYK stored inverted
+						rgb[0] = mul255(c0[x], k);
+						rgb[1] = mul255(c1[x], k);
+						rgb[2] = mul255(c2[x], k);
+					} else if (adobe_transform_ == 2) { // YCCK
+						if (n < 3) {
+							// (grey from YCCK: the inverted luma times K, no colour conversion)
+							o[0] = mul255(255 - c0[x], k);
+							if (n == 2) o[1] = 255;
+							continue;
 						}
-				}
-				if (!restart_check(&stop)) return false;
-				if (stop) return true;
-			}
-		return true;
-	}
-	void finish_progressive() {
-		for (int n = 0; n < img_n; ++n) {
-			Component &c = comp[n];
-			const int w = (c.x + 7) >> 3, h = (c.y + 7) >> 3;
-			for (int j = 0; j < h; ++j)
-				for (int i = 0; i < w; ++i) {
-					int16_t *data = &c.coeff[64 * ((size_t)i + (size_t)j * c.coeff_w)];
-					for (int q = 0; q < 64; ++q) data[q] = (int16_t)(data[q] * dequant[c.tq][q]);
-					idct_block(&c.data[(size_t)c.w2 * j * 8 + i * 8], c.w2, data);
-				}
-		}
-	}
-	bool decode_image() {
-		restart_interval = 0;
-		if (!decode_header()) return false;
-		int m = get_marker();
-		while (m != 0xd9) {
-			if (m == 0xda) {
-				if (!process_scan_header()) return false;
-				if (!parse_entropy_coded_data()) return false;
-				if (marker == kMarkerNone) {
-					while (!at_eof()) { // zeros after the scan data
-						if (get8() == 255) { marker = get8(); break; }
+						ycc_to_rgb(c0[x], c1[x], c2[x], rgb);
+						rgb[0] = mul255(255 - rgb[0], k);
+						rgb[1] = mul255(255 - rgb[1], k);
+						rgb[2] = mul255(255 - rgb[2], k);
+					} else { // no Adobe marker: treated as YCbCr, fourth channel ignored
+						if (n < 3) {
+							o[0] = c0[x];
+							if (n == 2) o[1] = 255;
+							continue;
+						}
+						ycc_to_rgb(c0[x], c1[x], c2[x], rgb);
 					}
 				}
-			} else if (m == 0xdc) {
-				const int Ld = get16(), NL = get16();
-				if (Ld != 4) return fail("bad DNL len");
-				if (NL != img_y) return fail("bad DNL height");
-			} else if (!process_marker(m)) {
-				return false;
+				if (n >= 3) {
+					o[0] = rgb[0];
+					o[1] = rgb[1];
+					o[2] = rgb[2];
+					if (n == 4) o[3] = 255;
+				} else {
+					o[0] = luma(rgb[0], rgb[1], rgb[2]);
+					if (n == 2) o[1] = 255;
+				}
 			}
-			m = get_marker();
 		}
-		if (progressive) finish_progressive();
-		return true;
 	}
 };
-
-// ---- chroma upsampling of one row; `near` is the sample row closer to the output row
-inline uint8_t div4(int x) { return (uint8_t)(x >> 2); }
-inline uint8_t div16(int x) { return (uint8_t)(x >> 4); }
-
-const uint8_t *resample_row(uint8_t *out, const uint8_t *near, const uint8_t *far, int w, int hs, int vs) {
-	if (hs == 1 && vs == 1) return near;
-	if (hs == 1 && vs == 2) {
-		for (int i = 0; i < w; ++i) out[i] = div4(3 * near[i] + far[i] + 2);
-		return out;
-	}
-	if (hs == 2 && vs == 1) {
-		if (w == 1) { out[0] = out[1] = near[0]; return out; }
-		out[0] = near[0];
-		out[1] = div4(near[0] * 3 + near[1] + 2);
-		int i;
-		for (i = 1; i < w - 1; ++i) {
-			const int n = 3 * near[i] + 2;
-			out[i * 2 + 0] = div4(n + near[i - 1]);
-			out[i * 2 + 1] = div4(n + near[i + 1]);
-		}
-		out[i * 2 + 0] = div4(near[w - 2] * 3 + near[w - 1] + 2);
-		out[i * 2 + 1] = near[w - 1];
-		return out;
-	}
-	if (hs == 2 && vs == 2) {
-		if (w == 1) { out[0] = out[1] = div4(3 * near[0] + far[0] + 2); return out; }
-		int t1 = 3 * near[0] + far[0];
-		out[0] = div4(t1 + 2);
-		for (int i = 1; i < w; ++i) {
-			const int t0 = t1;
-			t1 = 3 * near[i] + far[i];
-			out[i * 2 - 1] = div16(3 * t0 + t1 + 8);
-			out[i * 2] = div16(3 * t1 + t0 + 8);
-		}
-		out[w * 2 - 1] = div4(t1 + 2);
-		return out;
-	}
-	for (int i = 0; i < w; ++i)
-		for (int j = 0; j < hs; ++j) out[i * hs + j] = near[i];
-	return out;
-}
-
-inline void ycbcr_to_rgb(uint8_t *out, int y, int cb_, int cr_) {
-#define HMRM_F2FIX(x) (((int)((x)*4096.0f + 0.5f)) << 8)
-	const int y_fixed = (y << 20) + (1 << 19);
-	const int cr = cr_ - 128, cb = cb_ - 128;
-	int r = y_fixed + cr * HMRM_F2FIX(1.40200f);
-	int g = y_fixed + (cr * -HMRM_F2FIX(0.71414f)) + ((cb * -HMRM_F2FIX(0.34414f)) & 0xffff0000);
-	int b = y_fixed + cb * HMRM_F2FIX(1.77200f);
-#undef HMRM_F2FIX
-	r >>= 20; g >>= 20; b >>= 20;
-	if ((unsigned)r > 255) r = r < 0 ? 0 : 255;
-	if ((unsigned)g > 255) g = g < 0 ? 0 : 255;
-	if ((unsigned)b > 255) b = b < 0 ? 0 : 255;
-	out[0] = (uint8_t)r; out[1] = (uint8_t)g; out[2] = (uint8_t)b;
-}
-inline uint8_t blinn(uint8_t x, uint8_t y) {
-	const unsigned t = (unsigned)x * y + 128;
-	return (uint8_t)((t + (t >> 8)) >> 8);
-}
-inline uint8_t luma(int r, int g, int b) { return (uint8_t)(((r * 77) + (g * 150) + (29 * b)) >> 8); }
 
 } // namespace
 
-bool decode_jpeg(const uint8_t *bytes, size_t len, int req_comp, Image *img, std::string *err) {
-	std::vector<Decoder> holder(1); // the decoder is large: keep it off the stack
-	Decoder &z = holder[0];
-	z.p = bytes;
-	z.end = bytes + len;
-	memset(z.dequant, 0, sizeof z.dequant);
-	for (auto &h : z.huff_dc) { memset(&h, 0, sizeof h); }
-	for (auto &h : z.huff_ac) { memset(&h, 0, sizeof h); }
-	if (!z.decode_image()) {
-		*err = z.err.empty() ? "Corrupt JPEG" : z.err;
+bool decode_jpeg(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err) {
+	if (req_comp < 0 || req_comp > 4) {
+		*err = "bad req_comp";
 		return false;
 	}
-	const int n = req_comp ? req_comp : (z.img_n >= 3 ? 3 : 1);
-	const bool is_rgb = z.img_n == 3 && (z.rgb == 3 || (z.app14 == 0 && !z.jfif));
-	const int decode_n = (z.img_n == 3 && n < 3 && !is_rgb) ? 1 : z.img_n;
-	const int W = z.img_x, H = z.img_y;
-
-	struct Resample { int hs, vs, ystep, w_lores, ypos; size_t line0, line1; };
-	Resample rs[4];
-	std::vector<uint8_t> linebuf[4];
-	for (int k = 0; k < decode_n; ++k) {
-		linebuf[k].assign((size_t)W + 3 + 8, 0);
-		rs[k].hs = z.h_max / z.comp[k].h;
-		rs[k].vs = z.v_max / z.comp[k].v;
-		rs[k].ystep = rs[k].vs >> 1;
-		rs[k].w_lores = (W + rs[k].hs - 1) / rs[k].hs;
-		rs[k].ypos = 0;
-		rs[k].line0 = rs[k].line1 = 0;
-	}
-	img->w = W;
-	img->h = H;
-	img->comp = n;
-	img->comp_in_file = z.img_n >= 3 ? 3 : 1;
-	img->px.assign((size_t)n * W * H, 0);
-	const uint8_t *co[4] = {nullptr, nullptr, nullptr, nullptr};
-	for (int j = 0; j < H; ++j) {
-		uint8_t *out = &img->px[(size_t)n * W * j];
-		for (int k = 0; k < decode_n; ++k) {
-			Resample &r = rs[k];
-			const Component &c = z.comp[k];
-			const bool y_bot = r.ystep >= (r.vs >> 1);
-			const uint8_t *l0 = c.data.data() + r.line0, *l1 = c.data.data() + r.line1;
-			co[k] = resample_row(linebuf[k].data(), y_bot ? l1 : l0, y_bot ? l0 : l1, r.w_lores, r.hs, r.vs);
-			if (++r.ystep >= r.vs) {
-				r.ystep = 0;
-				r.line0 = r.line1;
-				if (++r.ypos < c.y) r.line1 += (size_t)c.w2;
-			}
-		}
-		if (n >= 3) {
-			if (z.img_n == 3) {
-				for (int i = 0; i < W; ++i, out += n) {
-					if (is_rgb) { out[0] = co[0][i]; out[1] = co[1][i]; out[2] = co[2][i]; }
-					else ycbcr_to_rgb(out, co[0][i], co[1][i], co[2][i]);
-					if (n == 4) out[3] = 255;
-				}
-			} else if (z.img_n == 4) {
-				for (int i = 0; i < W; ++i, out += n) {
-					const uint8_t m = co[3][i];
-					if (z.app14 == 0) { // CMYK
-						out[0] = blinn(co[0][i], m); out[1] = blinn(co[1][i], m); out[2] = blinn(co[2][i], m);
-					} else {
-						ycbcr_to_rgb(out, co[0][i], co[1][i], co[2][i]);
-						if (z.app14 == 2) { // YCCK
-							out[0] = blinn((uint8_t)(255 - out[0]), m);
-							out[1] = blinn((uint8_t)(255 - out[1]), m);
-							out[2] = blinn((uint8_t)(255 - out[2]), m);
-						}
-					}
-					if (n == 4) out[3] = 255;
-				}
-			} else {
-				for (int i = 0; i < W; ++i, out += n) {
-					out[0] = out[1] = out[2] = co[0][i];
-					if (n == 4) out[3] = 255;
-				}
-			}
-		} else {
-			for (int i = 0; i < W; ++i, out += n) {
-				if (is_rgb) out[0] = luma(co[0][i], co[1][i], co[2][i]);
-				else if (z.img_n == 4 && z.app14 == 0)
-					out[0] = luma(blinn(co[0][i], co[3][i]), blinn(co[1][i], co[3][i]), blinn(co[2][i], co[3][i]));
-				else if (z.img_n == 4 && z.app14 == 2) out[0] = blinn((uint8_t)(255 - co[0][i]), co[3][i]);
-				else out[0] = co[0][i];
-				if (n == 2) out[1] = 255;
-			}
-		}
+	try {
+		JpegDecoder dec(bytes, len);
+		dec.decode(req_comp, out);
+	} catch (const Fail &f) {
+		*err = f.why;
+		return false;
+	} catch (const std::bad_alloc &) {
+		*err = "out of memory";
+		return false;
 	}
 	return true;
 }

@@ -264,14 +264,14 @@ int          hmrm_config_take_heightmap_dirty(hmrm_config *cfg);
 int          hmrm_config_create_scene(const hmrm_config *cfg, hmrm_scene **out);
 
 /* ----------------------------------------------------------------- image IO */
-/* Replaces stbi_load(path,&w,&h,&n,req_comp) (hmap.cpp:320-321,341-342) for the
- * formats implemented natively: PNG (all colour types / bit depths, interlaced
- * too), JPEG (baseline and progressive Huffman, 8-bit; grey, YCbCr, RGB, CMYK/YCCK),
- * BMP (1/4/8-bit palette, 16/24/32-bit, bitfields), TGA (types 1/2/3/9/10/11), GIF (first
- * frame), PSD (RGB, 8/16-bit, raw or PackBits), Softimage PIC, Radiance HDR (to 8 bit with stb's
- * gamma 2.2) and binary PNM (P5/P6): every format stb_image v2.27 loads.  Pixels equal stb_image v2.27's for every req_comp.  Channel conversion follows stb_image v2.27
- * (16-bit -> 8 by >>8; grey -> RGB replicate; missing alpha = 255).  *out is
- * malloc'ed; free with hmrm_image_free. */
+/* Replaces stbi_load(path,&w,&h,&n,req_comp) (hmap.cpp:320-321,341-342) for the formats decoded
+ * natively: PNG (all colour types / bit depths, interlaced too), JPEG (baseline, extended and
+ * progressive Huffman, 8-bit; grey, YCbCr, RGB, CMYK/YCCK), BMP (1/4/8-bit palette, 16/24/32-bit,
+ * bit fields), TGA (types 1/2/3/9/10/11) and binary PNM (P5/P6).  Pixels equal stb_image v2.27's
+ * for every req_comp (16-bit -> 8 by >>8; grey -> RGB replicate; missing alpha = 255).  The other
+ * formats the reference's stb reads (GIF, PSD, PIC, Radiance HDR; README.md:75) are refused with
+ * HMRM_E_IMAGE and a message naming them; an embedder can decode such a map elsewhere and hand the
+ * pixels to hmrm_scene_create.  *out is malloc'ed; free with hmrm_image_free. */
 int  hmrm_image_load(const char *path, int32_t req_comp,
                      uint8_t **out, int32_t *w, int32_t *h, int32_t *comp_in_file);
 int  hmrm_image_load_memory(const uint8_t *bytes, size_t len, int32_t req_comp,

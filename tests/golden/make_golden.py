@@ -352,21 +352,6 @@ def make_jpeg_decode(ref):
     print("jpeg_decode.npz:", len(files), "files")
 
 
-def make_more_formats(ref):
-    import more_format_fixtures
-    files = more_format_fixtures.fixture_files()
-    out = {}
-    for name, data in files.items():
-        key = name.replace("/", ".")
-        out[key + "/bytes"] = np.frombuffer(data, dtype=np.uint8)
-        for req in range(5):
-            arr, n = ref.load(data, req)
-            assert arr is not None, (name, req, n)
-            out[f"{key}/req{req}"] = arr
-            out[f"{key}/n{req}"] = np.array([n], dtype=np.int32)
-    np.savez_compressed(os.path.join(HERE, "more_formats.npz"), **out)
-    print("more_formats.npz:", len(files), "files")
-
 
 if __name__ == "__main__":
     make_frames()
@@ -378,4 +363,3 @@ if __name__ == "__main__":
     make_png_encode(ref)
     make_jpeg_decode(ref)
     make_bmp_tga_decode(ref)
-    make_more_formats(ref)
