@@ -8,7 +8,7 @@ Host-side mirror of the reference's interface for the hot path only
 """
 from .lib import (  # noqa: F401
     Camera, Config, HmrmError, Scene, SceneParams, Stats,
-    PERSPECTIVE, SPHERICAL, ORTHOGRAPHIC, NEAREST, BILINEAR,
+    PERSPECTIVE, SPHERICAL, ORTHOGRAPHIC, NEAREST, BILINEAR, NEAREST_F32,
     HMRM_OK, HMRM_E_ARG, HMRM_E_IO, HMRM_E_IMAGE, HMRM_E_CONFIG, HMRM_E_DEVICE, HMRM_E_NOTERM,
     EXPORTED_SYMBOLS, LIB_PATH,
     band_local_rows, debug_frame, degrees_to_rads, device_count, image_load, image_load_memory, kernel_src_sha,

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -130,6 +131,8 @@ struct hmrm_scene {
 	uint8_t *d_rgb = nullptr;   // W*H*3  base_heightmap_buf (hmap.cpp:51)
 	uint32_t *d_cmap = nullptr; // W*H    colormap_buf as packed RGBA (hmap.cpp:59)
 	double *d_thr = nullptr;    // W*H    heightmap_buf[i] + min_height
+	float *d_thr32 = nullptr;   // W*H    the same rounded to float ("float heights" mode), built on first use
+	bool thr32_valid = false;
 	double thr_max = 0.0;
 	double thr_max_bil = 0.0; // whole-map bound of the interpolated thresholds (bilinear mode)
 	bool bil_valid = false;
@@ -240,6 +243,7 @@ int check_camera(const hmrm_camera *cam) {
 	if ((int64_t)cam->width * cam->height > ((int64_t)1 << 31) / 4)
 		return fail(HMRM_E_ARG, "resolution too large (the reference indexes the framebuffer with int)");
 	if (cam->projection < 1 || cam->projection > 3) return fail(HMRM_E_ARG, "projection must be 1, 2 or 3");
+	if (cam->sampling > HMRM_NEAREST_F32) return fail(HMRM_E_ARG, "sampling must be 0 (nearest), 1 (bilinear) or 2 (nearest, float heights)");
 	return HMRM_OK;
 }
 
@@ -328,7 +332,20 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 			const int rc2 = ensure_bilinear_pyramid(s);
 			if (rc2 != HMRM_OK) return rc2;
 		}
-		fr.thr_max = cam->sampling == HMRM_BILINEAR ? s->thr_max_bil : s->thr_max;
+		if (cam->sampling == HMRM_NEAREST_F32 && !s->thr32_valid) {
+			// float copy of the threshold table; made on the scene's stream and waited for, the
+			// launch may be on another one
+			const int64_t n = (int64_t)s->map_w * s->map_h;
+			if (!s->d_thr32) HIP_TRY(hipMalloc((void **)&s->d_thr32, (size_t)n * sizeof(float)));
+			HIP_TRY(hmrm::launch_thr_to_float(s->d_thr, s->d_thr32, n, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream));
+			s->thr32_valid = true;
+		}
+		// whole-map bound of the thresholds the kernel compares with: a float threshold is at most the
+		// double maximum rounded UP to float (the pyramid's window maxima are rounded up already)
+		fr.thr_max = cam->sampling == HMRM_BILINEAR ? s->thr_max_bil
+		             : cam->sampling == HMRM_NEAREST_F32 ? (double)std::nextafterf((float)s->thr_max, HUGE_VALF)
+		                                                 : s->thr_max;
 		// the finest level whose windows have at least min_window cells (camera.cpp's hint)
 		fr.min_level = 0;
 		while (fr.min_level < hmrm::kMipLevels - 1 && (2 << hmrm::mip_stride_shift(fr.min_level)) < fr.min_window)
@@ -365,7 +382,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const Fra
 		return HMRM_OK;
 	}
 	const bool leap = s->knobs.kernel != 1;
-	HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters,
+	HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px, c->d_counters,
 	                                 d_steps, d_entry, stats, leap, c->stream));
 	return HMRM_OK;
 }
@@ -440,6 +457,7 @@ int run_update_heights(hmrm_scene *s) {
 		HIP_TRY(hmrm::launch_build_mip_up(s->d_mipbuf + s->mip_off[l - 1], s->mip_w[l - 1], s->mip_h[l - 1],
 		                                  s->d_mipbuf + s->mip_off[l], s->mip_w[l], s->mip_h[l], s->stream));
 	s->bil_valid = false; // rebuilt by the next bilinear frame
+	s->thr32_valid = false;
 	for (StreamCtx *c : s->ctxs)
 		for (FrameSlot &sl : c->slots) sl.valid = false;
 	unsigned long long key = 0;
@@ -571,6 +589,7 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (s->d_rgb) (void)hipFree(s->d_rgb);
 	if (s->d_cmap) (void)hipFree(s->d_cmap);
 	if (s->d_thr) (void)hipFree(s->d_thr);
+	if (s->d_thr32) (void)hipFree(s->d_thr32);
 	if (s->d_mipbuf) (void)hipFree(s->d_mipbuf);
 	if (s->d_mipbuf_bil) (void)hipFree(s->d_mipbuf_bil);
 	if (s->d_maxkey) (void)hipFree(s->d_maxkey);

@@ -197,6 +197,13 @@ bool Config::consume(std::istream &input, std::string *fatal) {
 			else if (v == "bilinear") sampling = 1;
 			else warn << "WARNING: Unknown sampling: " << v << "\n";
 			log << "sampling " << (sampling == 1 ? "bilinear" : "nearest") << "\n";
+		} else if (next == "heights") { // additive: float thresholds for the nearest-cell lookup (not parity)
+			std::string v;
+			input >> v;
+			if (v == "f32") sampling = 2;
+			else if (v == "f64") sampling = sampling == 2 ? 0 : sampling;
+			else warn << "WARNING: Unknown heights type: " << v << "\n";
+			log << "heights " << (sampling == 2 ? "f32" : "f64") << "\n";
 		} else if (next == "devices") { // additive: multi-GPU recording (BASELINE config C5)
 			input >> devices;
 			if (devices < 0) devices = 1;

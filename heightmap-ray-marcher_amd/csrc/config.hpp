@@ -36,7 +36,7 @@ struct Config {
 	int record_mode = 0;
 	// additive: `devices n` -- GPUs the recording is sharded over, frame k on device k mod n (0 = all visible)
 	int devices = 1;
-	// additive: `sampling nearest|bilinear` (nearest = the reference's truncating lookup)
+	// additive: `sampling nearest|bilinear` (nearest = the reference's truncating lookup), `heights f32` (= 2)
 	int sampling = 0;
 
 	bool heightmap_dirty = false; // should_update_heightmap, sticky until taken

@@ -47,7 +47,7 @@ struct DevFrame {
 	const float *mipbuf_bil;     // the same pyramid over the 3x3-dilated table (bilinear quality mode)
 	int32_t mip_off[8];
 	int32_t diag_mode;           // tools only: what the instrumented kernel writes per pixel
-	int32_t sampling;            // 0 nearest cell (the reference), 1 bilinear quality mode
+	int32_t sampling;            // 0 nearest cell (the reference), 1 bilinear quality mode, 2 nearest cell with float thresholds
 	int32_t min_level;           // finest pyramid level worth an attempt (api.cpp, from min_window)
 	int32_t min_window;          // ... as a window size in cells (camera.cpp)
 	int32_t finest_pause;        // extra groups marched after a refused attempt at that level (camera.cpp)

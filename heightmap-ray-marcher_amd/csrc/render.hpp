@@ -25,10 +25,13 @@ hipError_t launch_render(const DevFrame &f, const RowMap &rows, const double *d_
 
 // Production kernel (render_fast.hip): speculative step groups, plus exact leaps over
 // empty pyramid blocks when `leap`.  Same outputs as launch_render.
-hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr,
+// f.sampling == 2 reads the float copy of the table (d_thr32, launch_thr_to_float) instead of d_thr.
+hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr, const float *d_thr32,
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
                               bool leap, hipStream_t stream);
+// thr32[i] = (float)thr[i], round to nearest (the "float heights" mode).
+hipError_t launch_thr_to_float(const double *d_thr, float *d_thr32, int64_t n, hipStream_t stream);
 // 3x3 maximum filter of the thr table (bounds every bilinear interpolation, render_fast.hip).
 hipError_t launch_dilate3x3(const double *d_thr, int w, int h, double *d_dst, hipStream_t stream);
 // Window-maximum pyramid (see render_fast.hip): level 0 from the thr table, level l+1 from level l.

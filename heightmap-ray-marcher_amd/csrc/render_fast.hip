@@ -109,12 +109,16 @@ __device__ __forceinline__ uint32_t shade_hit_bilinear(const DevFrame &f, const 
 #else
 #define HMRM_OCCUPANCY_ATTR
 #endif
-template <int PROJ, bool STATS, int GWM, bool LEAP, bool BILINEAR>
+// SAMP: 0 nearest cell (the reference), 1 bilinear quality mode, 2 nearest cell with float thresholds
+// (`thr` then points at the float copy of the table).
+template <int PROJ, bool STATS, int GWM, bool LEAP, int SAMP>
 __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR void k_render_fast(const DevFrame f, const RowMap rows,
                                                      const double *__restrict__ thr,
                                                      const uint32_t *__restrict__ cmap,
                                                      uint32_t *__restrict__ out, int64_t out_stride_px,
                                                      int tiles_y, StatsOut st) {
+	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
+	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
 	const PixelId pid = pixel_of_lane(f, rows, tiles_y);
 	const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull; // tools-only timing
 	unsigned long long my_steps = 0;
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 					}
 				} else {
 #pragma unroll
-					for (int j = 0; j < kGroup; ++j) T[j] = thr[cell[j]]; // hmap.cpp:1013-1014 (+ c0.z)
+					for (int j = 0; j < kGroup; ++j) T[j] = F32 ? (double)thr32[cell[j]] : thr[cell[j]]; // hmap.cpp:1013-1014 (+ c0.z)
 				}
 				if (budget >= kGroup) {
 					// in order: the first position that leaves the grid (:1006) or hits (:1016) ends the ray
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							b = bil_setup(qx, qy, f.map_w, f.map_h);
 							t = bil_mix(b, thr[b.c00], thr[b.c10], thr[b.c01], thr[b.c11]);
 						} else {
-							t = thr[c];
+							t = F32 ? (double)thr32[c] : thr[c];
 						}
 						if (zs < t) { // hmap.cpp:1016
 							rgba = BILINEAR ? shade_hit_bilinear(f, cmap, c, b) : shade_hit(f, cmap[c]);
@@ -627,10 +631,13 @@ static void launch_one(const DevFrame &f, const RowMap &rows, const double *d_th
                        uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid, int tiles_y,
                        hipStream_t stream) {
 	if (f.sampling == 1)
-		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, true>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, 1>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
+	else if (f.sampling == 2) // (d_thr is the float table here, see launch_render_fast)
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, 2>), grid, dim3(kBlockThreads), 0, stream, f, rows,
 		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
 	else
-		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, false>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, 0>), grid, dim3(kBlockThreads), 0, stream, f, rows,
 		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
 }
 
@@ -664,10 +671,23 @@ static void launch_proj(bool leap, const DevFrame &f, const RowMap &rows, const 
 	}
 }
 
-hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr,
+__global__ __launch_bounds__(256) void k_thr_to_float(const double *__restrict__ thr, float *__restrict__ dst, int64_t n) {
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)thr[i];
+}
+
+hipError_t launch_thr_to_float(const double *d_thr, float *d_thr32, int64_t n, hipStream_t stream) {
+	int64_t blocks = (n + 255) / 256;
+	if (blocks > 256 * 16) blocks = 256 * 16;
+	hipLaunchKernelGGL(k_thr_to_float, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, stream, d_thr, d_thr32, n);
+	return hipGetLastError();
+}
+
+hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr_f64, const float *d_thr32,
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
                               bool leap, hipStream_t stream) {
+	const double *d_thr = f.sampling == 2 ? reinterpret_cast<const double *>(d_thr32) : d_thr_f64;
 	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
 	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
 	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;

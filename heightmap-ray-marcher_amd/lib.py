@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libhmrm.so")
 HMRM_OK = 0
 HMRM_E_ARG, HMRM_E_IO, HMRM_E_IMAGE, HMRM_E_CONFIG, HMRM_E_DEVICE, HMRM_E_NOTERM = -1, -2, -3, -4, -5, -6
 PERSPECTIVE, SPHERICAL, ORTHOGRAPHIC = 1, 2, 3
-NEAREST, BILINEAR = 0, 1
+NEAREST, BILINEAR, NEAREST_F32 = 0, 1, 2
 _PROJ_NAMES = {"perspective": 1, "spherical": 2, "orthographic": 3}
 
 

@@ -49,10 +49,14 @@ enum {
  * build-side quality mode (north_star: "bilinear height/colour sampling"), not in the reference:
  * cell values sit at cell centres, thresholds and R,G,B are interpolated bilinearly in fp64
  * (definition: oracle/hmrm_oracle.c "bilinear quality mode"); additive config key
- * `sampling nearest|bilinear`. */
+ * `sampling nearest|bilinear`.  HMRM_NEAREST_F32 (north_star: "float heights") keeps the reference's
+ * loop and fp64 positions but compares against (float)(heightmap_buf[i] + min_height): a 4-byte
+ * threshold table; a ray's hit step can move where z is within half a float ulp of the threshold
+ * (tests bound it); additive config key `heights f64|f32`. */
 enum {
-	HMRM_NEAREST  = 0,
-	HMRM_BILINEAR = 1
+	HMRM_NEAREST     = 0,
+	HMRM_BILINEAR    = 1,
+	HMRM_NEAREST_F32 = 2   /* nearest cell, hit thresholds kept as float (half the table); not parity */
 };
 
 /* The globals UpdateHeightmap() and the box corners read:
@@ -75,7 +79,7 @@ typedef struct hmrm_camera {
 	int32_t  height;       /* screen_height */
 	int32_t  projection;   /* HMRM_PERSPECTIVE | HMRM_SPHERICAL | HMRM_ORTHOGRAPHIC */
 	uint8_t  bg_r, bg_g, bg_b;
-	uint8_t  sampling;     /* HMRM_NEAREST (0, the reference) | HMRM_BILINEAR (1, quality mode) */
+	uint8_t  sampling;     /* HMRM_NEAREST (0, the reference) | HMRM_BILINEAR (1) | HMRM_NEAREST_F32 (2) */
 	double   hfov;
 	double   hang;
 	double   vang;
@@ -237,7 +241,7 @@ int32_t hmrm_orbit_frame_owner(int32_t frame, int32_t n_devices);
  * every option to `echo_fd`-style sinks: echo text is appended to an internal
  * log retrievable with hmrm_config_log().  Additive keys (not in the reference,
  * named by north_star): `projection perspective|spherical|orthographic|1|2|3`,
- * `output <path.png|.ppm>`, `record orbit|off`, `devices n`, `sampling nearest|bilinear`.  Unknown key -> "WARNING: Unknown identifier: k". */
+ * `output <path.png|.ppm>`, `record orbit|off`, `devices n`, `sampling nearest|bilinear`, `heights f64|f32`.  Unknown key -> "WARNING: Unknown identifier: k". */
 hmrm_config *hmrm_config_create(void);
 void         hmrm_config_destroy(hmrm_config *cfg);
 /* Consume a whole stream; loads heightmap/colormap images when those keys

@@ -45,8 +45,17 @@ static v3 g_add(v3 a, v3 b) { v3 r = { a.x + b.x, a.y + b.y, a.z + b.z }; return
 static v3 g_sub(v3 a, v3 b) { v3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }
 static v3 g_neg(v3 a)       { v3 r = { -a.x, -a.y, -a.z }; return r; }
 static v3 g_smul(double s, v3 v) { v3 r = { s * v.x, s * v.y, s * v.z }; return r; }
+/* Sensitivity switch (tests/glm_sensitivity.py only; 0 everywhere else): glm is not under
+ * /root/reference, so the two formulas below are restated from its published source and nothing
+ * the reference holds pins them.  The alternatives a different glm release or build could have
+ * used are kept behind this switch to MEASURE how many pixels would move if the assumption were
+ * wrong: bit 0 = normalize as v / sqrt(dot) instead of v * (1 / sqrt(dot)); bit 1 = dot summed as
+ * x + (y + z) instead of (x + y) + z. */
+static int g_glm_variant = 0;
+void oracle_set_glm_variant(int v) { g_glm_variant = v; }
 static double g_dot(v3 a, v3 b) {
 	v3 t = { a.x * b.x, a.y * b.y, a.z * b.z };
+	if (g_glm_variant & 2) return t.x + (t.y + t.z);
 	return t.x + t.y + t.z;
 }
 static v3 g_cross(v3 x, v3 y) {
@@ -56,6 +65,11 @@ static v3 g_cross(v3 x, v3 y) {
 static v3 g_normalize(v3 v) {
 	double inv = 1.0 / sqrt(g_dot(v, v));
 	v3 r = { v.x * inv, v.y * inv, v.z * inv };
+	if (g_glm_variant & 1) {
+		const double len = sqrt(g_dot(v, v));
+		v3 q = { v.x / len, v.y / len, v.z / len };
+		return q;
+	}
 	return r;
 }
 /* dvec3 -> glm::vec3 (float) -> dvec3, per component, as the Orthographic ctor's
@@ -75,8 +89,9 @@ typedef struct {
 	double min_height, max_height;         /* :38-39 */
 	double grid_width, step_dist, ortho_width; /* :65,68,98 */
 	uint8_t bg_r, bg_g, bg_b;              /* :110-112 */
-	uint8_t sampling;   /* 0 = nearest cell (the reference, :1001-1018); 1 = bilinear quality mode
-	                       (NOT in the reference: a build-side addition, defined below) */
+	uint8_t sampling;   /* 0 = nearest cell (the reference, :1001-1018); 1 = bilinear quality mode;
+	                       2 = nearest cell with the hit thresholds rounded to float (neither is in the
+	                       reference: build-side additions, defined below) */
 	int64_t step_cap;   /* oracle-only guard: the reference loop is unbounded (:1000) */
 } oracle_cfg;
 
@@ -316,7 +331,10 @@ static int64_t shade_pixel(const oracle_cfg *c, const plane_t *pl, v3 c0, v3 c1,
 					real_hit = 1;
 					break;
 				}
-			} else if (int_point.z < heightmap_z + c0.z) {
+			} else if (c->sampling == 2 ? int_point.z < (double)(float)(heightmap_z + c0.z)
+			                            : int_point.z < heightmap_z + c0.z) {
+				/* sampling 2, "float heights" (north_star): the same loop, positions still fp64, but the
+				 * threshold of a cell is (float)(heightmap_buf[i] + hmap_c0.z), round to nearest */
 				int64_t red_index = (gridx + (int64_t)gridy * c->heightmap_width) * 4;
 				if (colormap_buf[red_index + 3] == 0) {
 					rgba[0] = c->bg_r; rgba[1] = c->bg_g; rgba[2] = c->bg_b;

@@ -55,6 +55,8 @@ def load(opt: str = "O2"):
         lib.oracle_degrees_to_rads.restype = C.c_double
         lib.oracle_degrees_to_rads.argtypes = [C.c_double]
         lib.oracle_max_threads.restype = C.c_int
+        lib.oracle_set_glm_variant.restype = None
+        lib.oracle_set_glm_variant.argtypes = [C.c_int]
         _libs[opt] = lib
     return _libs[opt]
 
@@ -117,3 +119,8 @@ def frame_record(cfg: OracleCfg, opt="O2") -> np.ndarray:
 
 def max_threads() -> int:
     return int(load().oracle_max_threads())
+
+
+def set_glm_variant(v: int, opt: str = "O2"):
+    """Sensitivity switch for the unpinned glm formulas (hmrm_oracle.c g_glm_variant); 0 = the assumed ones."""
+    load(opt).oracle_set_glm_variant(int(v))

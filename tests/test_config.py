@@ -158,6 +158,11 @@ def test_record_key_and_orbit_camera(hmrm, maps):
     cfg8 = hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} devices 8 record orbit")
     assert cfg8.devices == 8 and "devices 8" in cfg8.log
     assert hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} devices 0").devices == 0
+    # additive `heights f32`: float hit thresholds (camera.sampling = HMRM_NEAREST_F32); f64 is the default
+    c32 = hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} heights f32")
+    assert c32.camera().sampling == hmrm.NEAREST_F32 and "heights f32" in c32.log
+    assert hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} heights f32 heights f64").camera().sampling == hmrm.NEAREST
+    assert "Unknown heights type" in hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} heights f16").warnings
     wl = hmrm.synth.WORKLOADS["C5"]
     s = float(wl.map_size)
     static = wl.camera()

@@ -195,3 +195,29 @@ def test_bilinear_on_flat_map_equals_nearest_and_config_flag_defaults_off(oracle
         frames.append(oracle.render(cfg, heights, cmap, per_pixel=True))
     assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][3], frames[1][3])
     assert hmrm.Camera.make().sampling == hmrm.NEAREST
+
+
+def test_glm_sensitivity_switch(oracle, hmrm):
+    """The oracle's glm formulas are restated, not pinned.  The switch that swaps in the
+    alternatives (tests/glm_sensitivity.py, profiles/r02_glm_sensitivity.txt) changes last bits of ray
+    directions but, on this frame, no pixel; and it is off by default."""
+    import scenes
+    rgb, cmap = scenes.small_maps(64, 64, 3)
+    params = hmrm.SceneParams.make(0.0, 8.0, grid_width=1.0)
+    cam = hmrm.Camera.make(width=96, height=54, projection=1, hfov=hmrm.degrees_to_rads(90), hang=hmrm.degrees_to_rads(-45),
+                           vang=hmrm.degrees_to_rads(118), pos=(-10.0, 10.0, 24.0), step_dist=0.5)
+    heights = oracle.update_heightmap(rgb, params)
+    cfg = oracle.make_cfg(cam, params, 64, 64)
+    fb0, total0, _, steps0, entry0 = oracle.render(cfg, heights, cmap, per_pixel=True)
+    try:
+        changed_bits = 0
+        for v in (1, 2, 3):
+            oracle.set_glm_variant(v)
+            fb, total, _, steps, entry = oracle.render(cfg, heights, cmap, per_pixel=True)
+            changed_bits += int((entry.view(np.uint64) != entry0.view(np.uint64)).sum())
+            assert int((fb != fb0).any(axis=2).sum()) <= 2 and abs(total - total0) <= 8
+        assert changed_bits > 0, "the switch must reach the ray generator"
+    finally:
+        oracle.set_glm_variant(0)
+    fb, total, *_ = oracle.render(cfg, heights, cmap, per_pixel=True)
+    assert np.array_equal(fb, fb0) and total == total0

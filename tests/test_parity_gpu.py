@@ -589,6 +589,77 @@ def test_strips_over_rccl_two_gpus(gpu):
         assert line["n_gpus"] == 2 and line["value"] > 0
 
 
+def test_float_heights_mode_bit_exact_vs_its_oracle_definition(gpu, oracle):
+    """`heights f32` (HMRM_NEAREST_F32; north_star "float heights"): the reference's loop with fp64
+    positions and thresholds (float)(heightmap_buf[i] + min_height).  Its definition is the oracle's
+    (sampling 2) and the GPU matches it bit for bit -- frame, per-ray steps, distance() -- on every
+    edge scene and on random ones, through leaps and float-rounded window maxima."""
+    todo = [scenes.build_case(c) for c in scenes.cases()]
+    rng = np.random.RandomState(808)
+    for trial in range(16):
+        mw, mh = int(rng.choice([96, 257, 600])), int(rng.choice([131, 300]))
+        rgb, cmap = scenes.small_maps(mw, mh, 7000 + trial, color_heights=bool(trial % 2))
+        gw = float(rng.choice([1.0, 0.5, 0.3]))
+        hi = float(rng.uniform(3.0, 0.2 * mw)) * gw
+        params = gpu.SceneParams.make(float(rng.choice([0.0, -1.5])), hi, grid_width=gw)
+        ext = max(mw, mh) * gw
+        ang = rng.uniform(0, 2 * np.pi)
+        pos = (mw * gw / 2 + 0.9 * ext * np.cos(ang), -mh * gw / 2 + 0.9 * ext * np.sin(ang), hi * rng.uniform(1.0, 2.5))
+        cam = gpu.Camera.make(width=int(rng.randint(40, 160)), height=int(rng.randint(30, 100)), projection=int(rng.choice([1, 2, 3])),
+                              hfov=float(gpu.degrees_to_rads(rng.uniform(50, 170))),
+                              hang=float(np.arctan2(-mh * gw / 2 - pos[1], mw * gw / 2 - pos[0])),
+                              vang=float(gpu.degrees_to_rads(rng.uniform(95, 140))), pos=pos,
+                              ortho_width=float(rng.uniform(0.5, 3.0) * gw), step_dist=float(rng.choice([0.1, 0.25, 0.5]) * gw))
+        todo.append((f"fuzz{trial}", rgb, cmap, params, cam))
+    leaped = 0
+    with env(HMRM_STEP_CAP=300000):
+        for name, rgb, cmap, params, cam in todo:
+            cam.sampling = gpu.NEAREST_F32
+            scene = gpu.Scene(rgb, cmap, params)
+            heights = oracle.update_heightmap(rgb, params)
+            cfg = oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0], step_cap=300000)
+            ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True)
+            for variant in ("leap", "group"):
+                with kernel_variant(variant):
+                    fb, st, steps, entry = scene.render_stats(cam, per_pixel=True, allow_capped=True)
+                ok = osteps >= 0
+                assert np.array_equal(fb, ofb), (name, variant)
+                assert np.array_equal(steps.astype(np.int64)[ok], osteps[ok]) and st.steps == total, (name, variant)
+                assert np.array_equal(_bits(entry), _bits(oentry)) and st.capped == capped, (name, variant)
+            leaped += st.leaped_steps
+            if capped == 0:
+                assert np.array_equal(scene.render(cam), ofb), name
+            scene.close()
+    assert leaped > 0
+
+
+@pytest.mark.parametrize("wl_name", ["C2", "C3"])
+def test_float_heights_mode_tolerance_against_f64(gpu, wl_name):
+    """north_star's bar for float heights ("within 1 ULP on the hit-point t"), made concrete: the
+    slab-entry t is bit-identical (positions stay fp64); a threshold moves by at most half a float ulp
+    (relative 2^-24), so a ray's hit step changes only where z passed within that of the threshold:
+    at most a handful of rays per frame take a different number of steps, and the frames agree to
+    > 60 dB PSNR.  Tolerances written here: <= 1e-5 of the entering rays differ in step count."""
+    wl = gpu.synth.WORKLOADS[wl_name]
+    rgb, cmap = gpu.synth.synth_maps(wl.map_size)
+    params, cam = wl.scene_params(), wl.camera()
+    scene = gpu.Scene(rgb, cmap, params)
+    fb64, st64, steps64, entry64 = scene.render_stats(cam, per_pixel=True)
+    cam32 = wl.camera()
+    cam32.sampling = gpu.NEAREST_F32
+    fb32, st32, steps32, entry32 = scene.render_stats(cam32, per_pixel=True)
+    assert np.array_equal(_bits(entry32), _bits(entry64)), "slab-entry t must not depend on the height type"
+    entering = int((steps64 > 0).sum())
+    differ = int((steps32 != steps64).sum())
+    assert differ <= max(2, int(1e-5 * entering)), (differ, entering)
+    mse = float(((fb32.astype(np.float64) - fb64.astype(np.float64)) ** 2).mean())
+    psnr = float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+    assert psnr > 60.0, psnr
+    assert st32.capped == 0 and abs(int(st32.steps) - int(st64.steps)) <= 4096 * max(1, differ)
+    assert np.array_equal(scene.render(cam32), fb32)
+    scene.close()
+
+
 def test_progressive_cycle_refresh(gpu, oracle):
     """`cycle n` (hmap.cpp:976-983): each call rewrites pixels p = cycle (mod n); n calls give the frame."""
     rgb, cmap = scenes.small_maps(64, 64, 55)
