@@ -52,7 +52,7 @@ for k in range(count):
     cam = hm.Camera.make(width=int(rng.randint(1, 80)), height=int(rng.randint(1, 60)), projection=proj,
                          hfov=float(hm.degrees_to_rads(rng.uniform(5, 179))), hang=hang, vang=vang, pos=tuple(pos),
                          ortho_width=float(rng.uniform(0.05, 4.0) * gw), step_dist=sd,
-                         bg=tuple(int(v) for v in rng.randint(0, 256, size=3)), sampling=int(rng.randint(0, 4) == 0))
+                         bg=tuple(int(v) for v in rng.randint(0, 256, size=3)), sampling=int([0, 0, 0, 1, 2][int(rng.randint(0, 5))]))
     heights = oracle.update_heightmap(rgb, params)
     cfg = oracle.make_cfg(cam, params, mw, mh, step_cap=300000)
     ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True)

@@ -46,7 +46,7 @@ for k in range(count):
     cam = hm.Camera.make(width=int(rng.randint(40, 200)), height=int(rng.randint(30, 120)), projection=proj,
                          hfov=float(hm.degrees_to_rads(rng.uniform(20, 178))), hang=hang, vang=vang, pos=tuple(pos),
                          ortho_width=float(rng.uniform(0.5, 12.0) * gw), step_dist=sd,
-                         bg=(3, 2, 1), sampling=int(rng.randint(0, 5) == 0))
+                         bg=(3, 2, 1), sampling=int([0, 0, 0, 0, 1, 2][int(rng.randint(0, 6))]))
     cfg = oracle.make_cfg(cam, params, S, S, step_cap=CAP)
     ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True)
     fb, st, steps, entry = scene.render_stats(cam, per_pixel=True, allow_capped=True)
