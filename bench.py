@@ -177,7 +177,7 @@ def main():
     orbit = None
     if (world == 1 and not force_dist) or args.mode == "frames":
         out = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
-        if world == 1:
+        if world == 1 and not force_dist:
             def step():
                 scene.render_rows_device(cam, out.data_ptr(), W * 4, 0, H, stream=stream)
             my_steps_timed = frame_steps * args.steps
