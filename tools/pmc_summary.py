@@ -13,9 +13,11 @@ Units and corrections (MI355X_MICROARCH.md, HBM / rocprofv3 sections, and tools/
     uncalibrated width, so the raw figure is kept and twice the figure is listed as an upper bound.
   * SQ_ACTIVE_INST_VALU adds one unit (a quad-cycle) per VALU instruction whatever its class and four
     per fp64 transcendental (calibration: profiles/r02_valu_calibration.txt), so x4 it is the pipe
-    occupancy only if every instruction held the pipe for 4 cycles.  The weighted figure prices the
-    classes as measured with 8 waves per SIMD: 4 cycles for the fp64 add/mul/fma/compare/convert class,
-    16 for fp64 rcp/sqrt, 2.3 for the rest (32-bit integer / logic / select / move).
+    occupancy only if every instruction held the pipe for 4 cycles: an UPPER bound.  The weighted
+    figure prices the classes the counters can tell apart as measured with 8 waves per SIMD: 4.15
+    cycles for fp64 add/mul/fma, 16.2 for fp64 rcp/sqrt, 4.2 for conversions, 2.25 for everything else
+    -- a LOWER bound, because fp64 compares / min / max / fract, compares that write an SGPR pair,
+    v_mul_lo_u32 and VOP3 selects also take 4.1-4.2 cycles but are counted in no class of their own.
   * lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU).
 The JSON entry carries the hash of the kernel sources (lib.kernel_src_sha) so that bench.py can refuse
 numbers collected on another kernel."""
@@ -26,7 +28,7 @@ root, workload, out_prefix = sys.argv[1], sys.argv[2], sys.argv[3]
 
 SIMDS = 1024
 PEAK_CLOCK_HZ = 2.4e9
-CYC_F64, CYC_TRANS64, CYC_OTHER = 4.0, 16.0, 2.3
+CYC_F64, CYC_TRANS64, CYC_CVT, CYC_OTHER = 4.15, 16.2, 4.2, 2.25
 
 
 def product_kernel(name):
@@ -94,16 +96,16 @@ if "SQ_INSTS_VALU" in frame:
     n = frame["SQ_INSTS_VALU"]
     f64 = sum(frame.get("SQ_INSTS_VALU_" + c, 0.0) for c in ("ADD_F64", "MUL_F64", "FMA_F64"))
     trans = frame.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+    cvt = frame.get("SQ_INSTS_VALU_CVT", 0.0)
     have_classes = "SQ_INSTS_VALU_ADD_F64" in frame
     valu = {"insts": n, "f64_add_mul_fma": f64 if have_classes else None, "f64_trans": trans if have_classes else None,
+            "cvt": cvt if have_classes else None,
             "busy_cycles_upper": 4.0 * frame.get("SQ_ACTIVE_INST_VALU", n)}
     if have_classes:
-        # compares, conversions, min/max and moves of fp64 values are not in the three arithmetic
-        # counters but cost the fp64 rate: priced through the calibrated mix of the kernel's own ISA is
-        # not possible from counters, so they are counted at the cheaper rate (a LOWER bound)
-        valu["busy_cycles_weighted"] = CYC_F64 * f64 + CYC_TRANS64 * trans + CYC_OTHER * max(n - f64 - trans, 0.0)
+        valu["busy_cycles_weighted"] = (CYC_F64 * f64 + CYC_TRANS64 * trans + CYC_CVT * cvt +
+                                        CYC_OTHER * max(n - f64 - trans - cvt, 0.0))
     entry["valu"] = valu
-    lines.append(f"VALU per frame: {n:.0f} wave-instructions; fp64 add/mul/fma {f64:.0f}, fp64 rcp/sqrt {trans:.0f}")
+    lines.append(f"VALU per frame: {n:.0f} wave-instructions; fp64 add/mul/fma {f64:.0f}, fp64 rcp/sqrt {trans:.0f}, conversions {cvt:.0f}")
 if "SQ_THREAD_CYCLES_VALU" in frame and "SQ_ACTIVE_INST_VALU" in frame:
     entry["lane_util"] = frame["SQ_THREAD_CYCLES_VALU"] / (64.0 * frame["SQ_ACTIVE_INST_VALU"])
     lines.append(f"lane utilisation (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU): {entry['lane_util']:.3f}")

@@ -44,6 +44,10 @@ __global__ __launch_bounds__(256) void k_calib(double *out, int iters, double se
 	}
 	const double s = 1.0 + seed * 0x1p-30;
 	const float sf = (float)s;
+	const unsigned inv = (unsigned)(seed * 77.0) + threadIdx.x;
+	if (MODE == 20) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(inv), "v"((unsigned)iters) : "vcc");
+	if (MODE == 21 || MODE == 28 || MODE == 29) asm volatile("v_cmp_lt_u32 s[20:21], %0, %1" : : "v"(inv), "v"((unsigned)iters) : "s20", "s21");
+	if (MODE == 27) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(inv), "v"((unsigned)iters) : "vcc");
 	for (int it = 0; it < iters; ++it) {
 #pragma unroll
 		for (int u = 0; u < kUnroll; ++u) {
@@ -79,6 +83,18 @@ __global__ __launch_bounds__(256) void k_calib(double *out, int iters, double se
 				if (MODE == 17) asm volatile("v_cmp_lt_u32 s[20:21], %0, %1" : : "v"(c[i]), "v"(c[(i + 1) % kAcc]) : "s20", "s21");
 				if (MODE == 18) asm volatile("v_sqrt_f64 %0, %0" : "+v"(a[i]));
 				if (MODE == 19) asm volatile("v_div_fmas_f64 %0, %0, %1, %1" : "+v"(a[i]) : "v"(s) : "vcc");
+				// selects: condition in vcc (VOP2) or in an SGPR pair (VOP3), second source a loop invariant
+				if (MODE == 20) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(c[i]) : "v"(inv));
+				if (MODE == 21) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(c[i]) : "v"(inv));
+				if (MODE == 22) asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(c[i]) : "v"(c[(i + 1) % kAcc]), "v"(inv) : "vcc");
+				if (MODE == 23) asm volatile("v_cmp_lt_u32 s[20:21], %1, %2\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]" : "+v"(c[i]) : "v"(c[(i + 1) % kAcc]), "v"(inv) : "s20", "s21");
+				if (MODE == 25) asm volatile("v_cmp_lt_u32 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %1, %1, %3, vcc" : "+v"(c[i]), "+v"(c[(i + 3) % kAcc]) : "v"(c[(i + 1) % kAcc]), "v"(inv) : "vcc");
+				if (MODE == 26) asm volatile("v_cmp_lt_f64 s[20:21], %2, %3\n\tv_cndmask_b32_e64 %0, %0, %4, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %4, s[20:21]" : "+v"(c[i]), "+v"(c[(i + 3) % kAcc]) : "v"(a[i]), "v"(s), "v"(inv) : "s20", "s21");
+				if (MODE == 27) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(c[i]) : "v"(inv));
+				if (MODE == 28) asm volatile("s_and_b64 vcc, s[20:21], exec\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(c[i]) : "v"(inv) : "vcc", "scc");
+				if (MODE == 29) asm volatile("s_and_b64 s[22:23], s[20:21], exec\n\tv_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(c[i]) : "v"(inv) : "s22", "s23", "scc");
+				if (MODE == 30) asm volatile("v_cmp_lt_f64 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_add_u32 %1, %1, %4\n\tv_cndmask_b32 %1, %1, %4, vcc" : "+v"(c[i]), "+v"(c[(i + 3) % kAcc]) : "v"(a[i]), "v"(s), "v"(inv) : "vcc");
+				if (MODE == 24) asm volatile("v_cmp_lt_f64 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc" : "+v"(c[i]), "+v"(c[(i + 3) % kAcc]) : "v"(a[i]), "v"(s), "v"(inv) : "vcc");
 			}
 		}
 	}
@@ -136,6 +152,17 @@ int main(int argc, char **argv) {
 	if (run<17>("v_cmp_lt_u32 -> sgpr", d_out, blocks, iters, 1)) return 1;
 	if (run<18>("v_sqrt_f64", d_out, blocks, iters / 2, 1)) return 1;
 	if (run<19>("v_div_fmas_f64", d_out, blocks, iters, 1)) return 1;
+	if (run<20>("v_cndmask_b32 (vcc, const)", d_out, blocks, iters, 1)) return 1;
+	if (run<21>("v_cndmask_b32 (sgpr pair)", d_out, blocks, iters, 1)) return 1;
+	if (run<22>("v_cmp_u32->vcc + cndmask", d_out, blocks, iters, 2)) return 1;
+	if (run<23>("v_cmp_u32->sgpr + cndmask", d_out, blocks, iters, 2)) return 1;
+	if (run<24>("v_cmp_f64->vcc + 2 cndmask", d_out, blocks, iters / 2, 3)) return 1;
+	if (run<25>("v_cmp_u32->vcc + 2 cndmask", d_out, blocks, iters / 2, 3)) return 1;
+	if (run<26>("v_cmp_f64->sgpr + 2 cndmask_e64", d_out, blocks, iters / 2, 3)) return 1;
+	if (run<27>("v_cndmask_b32_e64 (vcc, const)", d_out, blocks, iters, 1)) return 1;
+	if (run<28>("s_and vcc + cndmask e32", d_out, blocks, iters, 1)) return 1;
+	if (run<29>("s_and sgpr + cndmask_e64", d_out, blocks, iters, 1)) return 1;
+	if (run<30>("cmp_f64->vcc, cnd, add, cnd", d_out, blocks, iters / 2, 4)) return 1;
 	CK(hipDeviceSynchronize());
 	return 0;
 }
