@@ -754,6 +754,59 @@ int hmrm_render_rows_device(const hmrm_scene *scene, const hmrm_camera *cam, voi
 	return launch_frame(s, c, f, slot, rows, (uint32_t *)d_rgba, (int64_t)(stride_bytes / 4), nullptr, nullptr, false);
 }
 
+// One frame over several scenes -- one per GPU, same maps (BASELINE config C4's sharding):
+// scene i renders the cyclic 16-row bands i, i+n, ... into a strip on its own device and copies each
+// band straight to its rows of the caller's frame over its own PCIe link; no exchange between devices
+// (a gather to one GPU first would funnel every byte through that GPU's link).  Launches of all
+// devices are enqueued before any is waited for.
+int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_camera *cam, uint8_t *rgba,
+                      size_t stride_bytes) {
+	int rc = check_camera(cam);
+	if (rc) return rc;
+	if (!scenes || n_scenes <= 0 || !rgba) return fail(HMRM_E_ARG, "NULL argument");
+	const size_t W = (size_t)cam->width;
+	const int H = cam->height;
+	if (stride_bytes < W * 4) return fail(HMRM_E_ARG, "stride_bytes < width*4");
+	constexpr int kBand = 16;
+	const int n = std::min<int>(n_scenes, (H + kBand - 1) / kBand);
+	for (int i = 0; i < n; ++i)
+		if (!scenes[i]) return fail(HMRM_E_ARG, "NULL scene");
+	for (int i = 0; i < n; ++i) {
+		hmrm_scene *s = scenes[i];
+		HIP_TRY(hipSetDevice(s->device));
+		std::lock_guard<std::mutex> lk(s->mu);
+		const int32_t local = hmrm_band_local_rows(H, kBand, i, n);
+		if ((rc = ensure_frame(s, W * (size_t)local))) return rc;
+		StreamCtx *c = nullptr;
+		if ((rc = ctx_for(s, s->stream, &c))) return rc;
+		hmrm::DevFrame f;
+		FrameSlot *slot = nullptr;
+		if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
+		hmrm::RowMap rows{0, local, kBand, i, n, 0};
+		if ((rc = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;
+		// band b of this scene's strip is frame rows [(i + b*n) * kBand, ...): contiguous in both
+		for (int b = 0; (i + b * n) * kBand < H; ++b) {
+			const int row0 = (i + b * n) * kBand, nrows = std::min(kBand, H - row0);
+			HIP_TRY(hipMemcpy2DAsync(rgba + (size_t)row0 * stride_bytes, stride_bytes,
+			                         s->d_frame + (size_t)b * kBand * W, W * 4, W * 4, (size_t)nrows,
+			                         hipMemcpyDeviceToHost, s->stream));
+		}
+	}
+	unsigned long long capped = 0;
+	for (int i = 0; i < n; ++i) {
+		hmrm_scene *s = scenes[i];
+		HIP_TRY(hipSetDevice(s->device));
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		std::lock_guard<std::mutex> lk(s->mu);
+		StreamCtx *c = nullptr;
+		if ((rc = ctx_for(s, s->stream, &c))) return rc;
+		unsigned long long here = 0;
+		if ((rc = take_capped(c, &here))) return rc;
+		capped += here;
+	}
+	return capped ? noterm(capped) : HMRM_OK;
+}
+
 int hmrm_scene_take_capped(const hmrm_scene *scene, void *hip_stream, uint64_t *capped) {
 	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
 	if (!s || !capped) return fail(HMRM_E_ARG, "NULL argument");

@@ -96,15 +96,37 @@ int main(int argc, char *argv[]) {
 	}
 
 	std::vector<uint8_t> framebuf((size_t)cam.width * cam.height * 4);
-	hmrm_stats stats;
-	rc = hmrm_render_stats(scene, &cam, framebuf.data(), (size_t)cam.width * 4, &stats, NULL, NULL);
-	if (rc != HMRM_OK && rc != HMRM_E_NOTERM) {
-		std::cerr << hmrm_last_error() << "\n";
-		return 1;
+	int want_dev = hmrm_config_devices(cfg);
+	const int visible_dev = hmrm_device_count();
+	if (want_dev <= 0 || want_dev > visible_dev) want_dev = visible_dev > 0 ? visible_dev : 1;
+	if (want_dev > 1) {
+		// `devices n`: the frame's 16-row bands are dealt out over n GPUs (BASELINE config C4)
+		std::vector<hmrm_scene *> scenes(1, scene);
+		for (int d = 1; d < want_dev && rc == HMRM_OK; ++d) {
+			hmrm_scene *extra = NULL;
+			rc = hmrm_set_device(d);
+			if (rc == HMRM_OK) rc = hmrm_config_create_scene(cfg, &extra);
+			if (rc == HMRM_OK) scenes.push_back(extra);
+		}
+		if (rc == HMRM_OK) rc = hmrm_render_multi(scenes.data(), (int32_t)scenes.size(), &cam, framebuf.data(), (size_t)cam.width * 4);
+		for (size_t i = 1; i < scenes.size(); ++i) hmrm_scene_destroy(scenes[i]);
+		if (rc != HMRM_OK && rc != HMRM_E_NOTERM) {
+			std::cerr << hmrm_last_error() << "\n";
+			return 1;
+		}
+		if (rc == HMRM_E_NOTERM) std::cerr << "WARNING: " << hmrm_last_error() << "\n";
+		std::cout << "rendered " << (long long)cam.width * cam.height << " rays on " << want_dev << " devices\n";
+	} else {
+		hmrm_stats stats;
+		rc = hmrm_render_stats(scene, &cam, framebuf.data(), (size_t)cam.width * 4, &stats, NULL, NULL);
+		if (rc != HMRM_OK && rc != HMRM_E_NOTERM) {
+			std::cerr << hmrm_last_error() << "\n";
+			return 1;
+		}
+		if (rc == HMRM_E_NOTERM) std::cerr << "WARNING: " << hmrm_last_error() << "\n";
+		std::cout << "rendered " << stats.rays << " rays, " << stats.steps << " ray-steps, " << stats.hits
+		          << " hits in " << hmrm_last_kernel_ms() << " ms (kernel)\n";
 	}
-	if (rc == HMRM_E_NOTERM) std::cerr << "WARNING: " << hmrm_last_error() << "\n";
-	std::cout << "rendered " << stats.rays << " rays, " << stats.steps << " ray-steps, " << stats.hits
-	          << " hits in " << hmrm_last_kernel_ms() << " ms (kernel)\n";
 
 	std::string path = hmrm_config_output_path(cfg);
 	if (path.empty()) {

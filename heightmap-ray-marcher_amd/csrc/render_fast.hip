@@ -169,10 +169,9 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 			}
 			int cooldown = 0, fails = 0;
 			Axis ax, ay, az;
-			ax.key = ay.key = az.key = 0xfffffffeu; // never matches: forces the first refresh
-			ax.delta = ay.delta = az.delta = 0.0;
-			ax.lim = ay.lim = az.lim = 0.0;
-			ax.rdel = ay.rdel = az.rdel = 0.0;
+			axis_init(ax, sx);
+			axis_init(ay, sy);
+			axis_init(az, sz);
 			// window choice: step back one half-window when the cell index decreases along the ray
 			const int offx = sx < 0.0 ? 1 : 0, offy = sy > 0.0 ? 1 : 0; // gy = trunc(-y/gw) falls when y grows
 			const double gwid = (GWM == 0) ? 1.0 : f.grid_width;
@@ -191,6 +190,17 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 					if (attempt) {
 						if (STATS) ++dg_attempts;
 						dg_attempted = true;
+						if (STATS && f.diag_mode == 16) { // how often does a WAVE run a refresh block, and for how many lanes?
+							const unsigned long long act = __ballot(true);
+							const unsigned long long bx = __ballot((hi32(x) >> 20) != ax.key), by = __ballot((hi32(y) >> 20) != ay.key),
+							                         bz = __ballot((hi32(z) >> 20) != az.key);
+							if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
+								dg_x0 += 1u;                                                  // attempt blocks run by waves
+								dg_x1 += (bx ? 1u : 0u) + (by ? 1u : 0u) + (bz ? 1u : 0u);    // refresh blocks run by waves
+								dg_x2 += (unsigned)(__popcll(bx) + __popcll(by) + __popcll(bz)); // lanes that needed them
+								dg_x3 += (unsigned)__popcll(act);                             // lanes in the attempt blocks
+							}
+						}
 						if ((hi32(x) >> 20) != ax.key) axis_refresh(ax, x, sx);
 						if ((hi32(y) >> 20) != ay.key) axis_refresh(ay, y, sy);
 						if ((hi32(z) >> 20) != az.key) axis_refresh(az, z, sz);

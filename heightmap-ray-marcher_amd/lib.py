@@ -101,6 +101,7 @@ def _load():
         "hmrm_scene_read_heights": (C.c_int, [vp, vp]),
         "hmrm_render": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t]),
         "hmrm_render_cycle": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, i32, i32]),
+        "hmrm_render_multi": (C.c_int, [C.POINTER(vp), i32, C.POINTER(Camera), vp, C.c_size_t]),
         "hmrm_render_rows_device": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, i32, i32, i32, i32, i32, vp]),
         "hmrm_scene_take_capped": (C.c_int, [vp, vp, C.POINTER(C.c_uint64)]),
         "hmrm_debug_reload_env": (C.c_int, [vp]),
@@ -365,6 +366,17 @@ def record_orbit_multi(scenes, base: Camera, centre_x, centre_y, radius, hang0, 
     _check(lib.hmrm_record_orbit_multi(arr, len(scenes), C.byref(base), centre_x, centre_y, radius, hang0, frames,
                                        os.fsencode(directory), rec_id, encoder_threads, int(verbose)),
            allow=(HMRM_E_NOTERM,))
+
+
+def render_multi(scenes, cam: Camera, allow_capped=False) -> np.ndarray:
+    """One frame over several scenes (one per GPU): scene i renders the cyclic 16-row bands i, i+n, ..."""
+    for s in scenes:
+        s._sync_env()
+    arr = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    fb = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
+    _check(lib.hmrm_render_multi(arr, len(scenes), C.byref(cam), _ptr(fb), cam.width * 4),
+           allow=(HMRM_E_NOTERM,) if allow_capped else ())
+    return fb
 
 
 def orbit_frame_owner(frame: int, n_devices: int) -> int:

@@ -134,6 +134,14 @@ int  hmrm_scene_read_heights(const hmrm_scene *scene, double *out);
 int hmrm_render(const hmrm_scene *scene, const hmrm_camera *cam,
                 uint8_t *rgba, size_t stride_bytes);
 
+/* The same frame rendered by several scenes at once -- one per GPU, each created after
+ * hmrm_set_device(i) with the same maps (BASELINE config C4's sharding of main/hmap.cpp:978-983's
+ * independent pixels): scene i renders the cyclic 16-row bands i, i+n, ... and copies them to their
+ * rows of `rgba` over its own PCIe link; no exchange between devices.  Same pixels and return
+ * codes as hmrm_render. */
+int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_camera *cam,
+                      uint8_t *rgba, size_t stride_bytes);
+
 /* The same frame without blocking: hmrm_render_begin enqueues the kernel and the device-to-host
  * copy into a pinned frame owned by the scene and returns a ticket; hmrm_render_wait blocks until
  * that frame is in host memory and lends it out (*rgba, valid until hmrm_render_release; returns

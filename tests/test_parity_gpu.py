@@ -519,6 +519,32 @@ def test_recording_sharded_over_scenes(gpu, oracle, tmp_path):
     one.close()
 
 
+def test_one_frame_over_several_scenes(gpu, oracle):
+    """hmrm_render_multi (BASELINE config C4's sharding in the C ABI): 2, 3 and 5 scenes, each rendering
+    its cyclic 16-row bands and copying them to their rows of the host frame, give the single-scene
+    frame and the oracle's -- ragged height, all projections, and a capped scene reports its rays."""
+    rgb, cmap = scenes.small_maps(128, 128, 29)
+    params = gpu.SceneParams.make(0.0, 12.0, grid_width=1.0)
+    heights = oracle.update_heightmap(rgb, params)
+    many = [gpu.Scene(rgb, cmap, params) for _ in range(5)]
+    for proj in (1, 2, 3):
+        cam = gpu.Camera.make(width=211, height=117, projection=proj, hfov=gpu.degrees_to_rads(150 if proj == 2 else 85),
+                              hang=gpu.degrees_to_rads(-45), vang=gpu.degrees_to_rads(112), pos=(-40.0, 40.0, 50.0),
+                              ortho_width=0.9, step_dist=0.25, bg=(5, 6, 7))
+        ofb, *_ = oracle.render(oracle.make_cfg(cam, params, 128, 128), heights, cmap)
+        assert np.array_equal(many[0].render(cam), ofb)
+        for n in (2, 3, 5):
+            assert np.array_equal(gpu.render_multi(many[:n], cam), ofb), (proj, n)
+    with env(HMRM_STEP_CAP=50):
+        cam = gpu.Camera.make(width=64, height=40, projection=1, hang=gpu.degrees_to_rads(-45), vang=gpu.degrees_to_rads(112),
+                              pos=(-40.0, 40.0, 50.0), step_dist=0.05)
+        with pytest.raises(gpu.HmrmError) as e:
+            gpu.render_multi(many[:3], cam)
+        assert e.value.code == gpu.HMRM_E_NOTERM
+    for sc in many:
+        sc.close()
+
+
 def test_two_streams_two_spherical_cameras(gpu, oracle):
     """hmrm_render_rows_device from two HIP streams with two different spherical cameras, alternating
     without a host sync in between: each stream has its own tables / counters (api.cpp StreamCtx), so
