@@ -574,6 +574,52 @@ def test_two_streams_two_spherical_cameras(gpu, oracle):
     scene.close()
 
 
+def test_two_host_threads_share_one_scene(gpu, oracle):
+    """SURVEY 8(b) "Threading": two host threads drive one scene at the same time, each on its own HIP
+    stream with its own cameras (spherical and perspective, so per-frame tables are in play); every frame
+    equals the oracle's.  The scene serialises only the host-side set-up, not the launches."""
+    import threading
+    import torch
+    rgb, cmap = scenes.small_maps(128, 128, 67)
+    params = gpu.SceneParams.make(0.0, 12.0, grid_width=1.0)
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    W, H = 256, 144
+    base = gpu.Camera.make(width=W, height=H, projection=2, hfov=gpu.degrees_to_rads(160), hang=0.0,
+                           vang=gpu.degrees_to_rads(110), pos=(-40.0, 40.0, 50.0), step_dist=0.25, bg=(1, 2, 3))
+    cams = []
+    for k in range(6):
+        c = gpu.orbit_camera(base, 64.0, -64.0, 120.0, gpu.degrees_to_rads(-45.0), k, 6)
+        c.projection = 2 if k % 2 == 0 else 1
+        c.hfov = gpu.degrees_to_rads(160 if k % 2 == 0 else 80)
+        cams.append(c)
+    want = [oracle.render(oracle.make_cfg(c, params, 128, 128), heights, cmap)[0] for c in cams]
+    errors = []
+
+    def worker(tid):
+        try:
+            torch.cuda.set_device(0)
+            gpu.set_device(0)
+            stream = torch.cuda.Stream()
+            for rep in range(8):
+                for k in range(tid, 6, 2):
+                    buf = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+                    scene.render_rows_device(cams[k], buf.data_ptr(), W * 4, 0, H, stream=stream.cuda_stream)
+                    stream.synchronize()
+                    if not np.array_equal(buf.cpu().numpy(), want[k]):
+                        errors.append((tid, rep, k))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    scene.close()
+
+
 def test_rows_device_reports_capped_rays(gpu):
     """The asynchronous strip entry cannot return HMRM_E_NOTERM itself; hmrm_scene_take_capped does,
     once, for the launches of that stream (the cap must never be silent)."""
