@@ -78,7 +78,7 @@ Knobs read_knobs() {
 } // namespace
 
 constexpr int kCostRows = 8;
-constexpr int kFrameSlots = 4;   // cached per-frame records (and spherical tables) per stream
+constexpr int kFrameSlots = 32;  // cached per-frame records (and spherical tables) per stream: a 64-frame orbit over 2+ GPUs fits
 constexpr int kMaxStreamCtx = 8; // streams a scene keeps launch state for
 
 // One cached per-frame record: the result of the host set-up (camera.cpp) for one camera, and for
