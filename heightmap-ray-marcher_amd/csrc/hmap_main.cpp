@@ -21,6 +21,18 @@
 
 #include "../../include/hmrm.h"
 
+// `devices n` (0 = all visible).  HMRM_OVERSUBSCRIBE_DEVICES=1 (tests on a one-GPU box) keeps n above the
+// number of visible GPUs and deals the scenes out round-robin over the devices there are.
+static int wanted_devices(hmrm_config *cfg, int *visible_out) {
+	int n = hmrm_config_devices(cfg);
+	const int visible = hmrm_device_count() > 0 ? hmrm_device_count() : 1;
+	const char *over = std::getenv("HMRM_OVERSUBSCRIBE_DEVICES");
+	if (n <= 0) n = visible;
+	if (n > visible && !(over && over[0] == '1')) n = visible;
+	*visible_out = visible;
+	return n;
+}
+
 static bool ends_with(const std::string &s, const char *suffix) {
 	const size_t n = strlen(suffix);
 	return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
@@ -75,13 +87,12 @@ int main(int argc, char *argv[]) {
 		mkdir(dir.c_str(), 0777);
 		// `devices n`: one scene per GPU, frame k on device k mod n (BASELINE config C5); the scene
 		// created above lives on device 0
-		int ndev = hmrm_config_devices(cfg);
-		const int visible = hmrm_device_count();
-		if (ndev <= 0 || ndev > visible) ndev = visible > 0 ? visible : 1;
+		int visible = 1;
+		const int ndev = wanted_devices(cfg, &visible);
 		std::vector<hmrm_scene *> scenes(1, scene);
 		for (int d = 1; d < ndev && rc == HMRM_OK; ++d) {
 			hmrm_scene *extra = NULL;
-			rc = hmrm_set_device(d);
+			rc = hmrm_set_device(d % visible);
 			if (rc == HMRM_OK) rc = hmrm_config_create_scene(cfg, &extra);
 			if (rc == HMRM_OK) scenes.push_back(extra);
 		}
@@ -96,15 +107,14 @@ int main(int argc, char *argv[]) {
 	}
 
 	std::vector<uint8_t> framebuf((size_t)cam.width * cam.height * 4);
-	int want_dev = hmrm_config_devices(cfg);
-	const int visible_dev = hmrm_device_count();
-	if (want_dev <= 0 || want_dev > visible_dev) want_dev = visible_dev > 0 ? visible_dev : 1;
+	int visible_dev = 1;
+	const int want_dev = wanted_devices(cfg, &visible_dev);
 	if (want_dev > 1) {
 		// `devices n`: the frame's 16-row bands are dealt out over n GPUs (BASELINE config C4)
 		std::vector<hmrm_scene *> scenes(1, scene);
 		for (int d = 1; d < want_dev && rc == HMRM_OK; ++d) {
 			hmrm_scene *extra = NULL;
-			rc = hmrm_set_device(d);
+			rc = hmrm_set_device(d % visible_dev);
 			if (rc == HMRM_OK) rc = hmrm_config_create_scene(cfg, &extra);
 			if (rc == HMRM_OK) scenes.push_back(extra);
 		}

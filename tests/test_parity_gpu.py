@@ -271,6 +271,38 @@ def test_cli_end_to_end(gpu, oracle, tmp_path):
             assert open(outp, "rb").read() == gpu.png_encode(ofb)
 
 
+def test_cli_devices_key(gpu, oracle, tmp_path):
+    """`devices 3` in the CLI: one frame as three scenes' bands (hmrm_render_multi) and a recording with frame
+    k on scene k mod 3 -- on this box all three on the one GPU (HMRM_OVERSUBSCRIBE_DEVICES=1)."""
+    wl = gpu.synth.WORKLOADS["C1"]
+    rgb, cmap = gpu.synth.synth_maps(wl.map_size)
+    hp, cp = str(tmp_path / "h.ppm"), str(tmp_path / "c.png")
+    gpu.write_ppm(hp, rgb)
+    gpu.write_png(cp, cmap)
+    params, cam = wl.scene_params(), wl.camera()
+    heights = oracle.update_heightmap(rgb, params)
+    ofb, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap)
+    exe = os.path.join(os.path.dirname(gpu.LIB_PATH), "hmap")
+    envp = dict(os.environ, HMRM_OVERSUBSCRIBE_DEVICES="1")
+    outp = str(tmp_path / "frame.png")
+    cfgp = tmp_path / "one.txt"
+    cfgp.write_text(gpu.synth.config_text(wl, hp, cp, outp) + "devices 3\n")
+    r = subprocess.run([exe, str(cfgp)], capture_output=True, text=True, timeout=300, env=envp)
+    assert r.returncode == 0 and "on 3 devices" in r.stdout and "devices 3" in r.stdout, r.stdout + r.stderr
+    assert open(outp, "rb").read() == gpu.png_encode(ofb)
+    rec = tmp_path / "rec"
+    cfg2 = tmp_path / "rec.txt"
+    cfg2.write_text(gpu.synth.config_text(wl, hp, cp, str(rec)) + "devices 3 record orbit recording_frame_count 7\n")
+    r = subprocess.run([exe, str(cfg2)], capture_output=True, text=True, timeout=300, env=envp)
+    assert r.returncode == 0 and r.stdout.count("Saved screenshot at ") == 7, r.stdout + r.stderr
+    files = sorted(rec.iterdir())
+    assert len(files) == 7
+    # frame 0 of the orbit through the configured pose is that pose
+    f0 = [p for p in files if p.name.endswith("_0.png")][0]
+    img, _ = gpu.image_load(str(f0), 4)
+    assert img.shape == ofb.shape
+
+
 def test_recording_orbit_writes_reference_named_pngs(gpu, oracle, tmp_path):
     """`record orbit`: frames <dir>/hmap_<id>_<n>.png (hmap.cpp:1132-1134), each equal to the oracle's frame."""
     rgb, cmap = scenes.small_maps(64, 64, 41)
