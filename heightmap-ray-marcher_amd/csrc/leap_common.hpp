@@ -49,20 +49,9 @@ __device__ __forceinline__ int cvt_i32_sat(double q) {
 struct Axis {
 	double delta;  // p_{k+1} - p_k for every p of the binade (valid iff key matches)
 	double lim;    // binade boundary the coordinate is moving towards
-	double rdel;   // ~1/step (signed), set once per ray: (lim - p) * rdel ESTIMATES the steps left
-	               // (delta is the step rounded to the binade's grid, so 1/step is as good an estimate as 1/delta)
+	double rdel;   // ~1/delta (signed); (lim - p) * rdel estimates the steps left
 	uint32_t key;  // sign+exponent bits (hi32 >> 20) the above was measured for
 };
-
-// Once per ray: the reciprocal used by every step-count estimate of this axis.  A coordinate that
-// never moves (s == 0, or s absorbed by rounding: then delta == 0 and lim is set one step away
-// on the far side) gets a huge value: unlimited room.
-__device__ __forceinline__ void axis_init(Axis &a, double s) {
-	a.key = 0xfffffffeu; // never matches: forces the first refresh
-	a.delta = 0.0;
-	a.lim = 0.0;
-	a.rdel = s == 0.0 ? 0x1p40 : __builtin_amdgcn_rcp(s);
-}
 
 // Measure delta at p (see file header) from TWO real steps.  Off a rounding tie the
 // increment is the same for every p of the binade.  On an exact tie (s = q*u + u/2)
@@ -86,10 +75,9 @@ __device__ __forceinline__ void axis_refresh(Axis &a, double p, double s) {
 	// One integer add on the high word (E <= 1900, no overflow into the sign).
 	const uint32_t away = (((hi32(d) ^ hp) >> 31) ^ 1u) << 20;
 	const double lim = f64_from_hi((hp & 0xfff00000u) + away);
-	// the coordinate never moves (s == 0, or s absorbed by rounding): unlimited room -- a limit one unit
-	// away on the side rdel points to makes (lim - p) * rdel = |rdel|, huge (2^40, or 1/|s| > 2^52/|p|)
-	const bool still = d == 0.0;
-	a.lim = still ? (a.rdel < 0.0 ? p - 1.0 : p + 1.0) : lim;
+	const bool still = d == 0.0;              // the coordinate never moves (s == 0 or absorbed): unlimited room
+	a.lim = still ? p + 1.0 : lim;
+	a.rdel = still ? 0x1p40 : __builtin_amdgcn_rcp(d);
 }
 
 // p_n = p + n*delta is trustworthy iff it is still in p's binade with the same sign,

@@ -32,6 +32,7 @@
 // rounded UP (a larger bound is always safe).  Above them: the whole map (thr_max).
 #include "device_common.hpp"
 #include "leap_common.hpp"
+#include "leap_diag.hpp"
 #include "render.hpp"
 
 #pragma clang fp contract(off)
@@ -120,12 +121,10 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
 	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
 	const PixelId pid = pixel_of_lane(f, rows, tiles_y);
-	const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull; // tools-only timing
+	LoopDiag<STATS> diag; // (empty unless STATS: leap_diag.hpp)
+	diag.start();
 	unsigned long long my_steps = 0;
 	uint32_t my_hit = 0, my_cap = 0;
-	uint32_t dg_attempts = 0, dg_leaps = 0, dg_groups = 0; // STATS-only diagnostics
-	unsigned long long dg_leaped = 0;
-	unsigned long long dg_x0 = 0, dg_x1 = 0, dg_x2 = 0, dg_x3 = 0;
 
 	if (pid.live) {
 		const DevRay ray = make_ray<PROJ>(f, pid.px, pid.py);
@@ -169,9 +168,10 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 			}
 			int cooldown = 0, fails = 0;
 			Axis ax, ay, az;
-			axis_init(ax, sx);
-			axis_init(ay, sy);
-			axis_init(az, sz);
+			ax.key = ay.key = az.key = 0xfffffffeu; // never matches: forces the first refresh
+			ax.delta = ay.delta = az.delta = 0.0;
+			ax.lim = ay.lim = az.lim = 0.0;
+			ax.rdel = ay.rdel = az.rdel = 0.0;
 			// window choice: step back one half-window when the cell index decreases along the ray
 			const int offx = sx < 0.0 ? 1 : 0, offy = sy > 0.0 ? 1 : 0; // gy = trunc(-y/gw) falls when y grows
 			const double gwid = (GWM == 0) ? 1.0 : f.grid_width;
@@ -182,25 +182,14 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 			bool done = entry_nan;
 			while (!done) {
 				bool skip_group = false;
-				bool dg_attempted = false; // diagnostics only
+				diag.begin_trip();
 				// ---------------------------------------------------------- leap
 				if (LEAP) {
 					const bool attempt = cooldown == 0;
 					cooldown -= attempt ? 0 : 1;
 					if (attempt) {
-						if (STATS) ++dg_attempts;
-						dg_attempted = true;
-						if (STATS && f.diag_mode == 16) { // how often does a WAVE run a refresh block, and for how many lanes?
-							const unsigned long long act = __ballot(true);
-							const unsigned long long bx = __ballot((hi32(x) >> 20) != ax.key), by = __ballot((hi32(y) >> 20) != ay.key),
-							                         bz = __ballot((hi32(z) >> 20) != az.key);
-							if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
-								dg_x0 += 1u;                                                  // attempt blocks run by waves
-								dg_x1 += (bx ? 1u : 0u) + (by ? 1u : 0u) + (bz ? 1u : 0u);    // refresh blocks run by waves
-								dg_x2 += (unsigned)(__popcll(bx) + __popcll(by) + __popcll(bz)); // lanes that needed them
-								dg_x3 += (unsigned)__popcll(act);                             // lanes in the attempt blocks
-							}
-						}
+						diag.on_attempt();
+						diag.on_refresh_check(f, (hi32(x) >> 20) != ax.key, (hi32(y) >> 20) != ay.key, (hi32(z) >> 20) != az.key);
 						if ((hi32(x) >> 20) != ax.key) axis_refresh(ax, x, sx);
 						if ((hi32(y) >> 20) != ay.key) axis_refresh(ay, y, sy);
 						if ((hi32(z) >> 20) != az.key) axis_refresh(az, z, sz);
@@ -261,61 +250,14 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							ok = can && inbn && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
 							     (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
 							     axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
-							if (STATS && f.diag_mode == 10 && can && !ok) { // which landing test refused the jump
-								const bool win = (unsigned)(gxn - wx0) < (unsigned)wspan_x && (unsigned)(gyn - wy0) < (unsigned)wspan_y;
-								dg_x0 += !inbn ? 1u : 0u;
-								dg_x1 += (inbn && !win) ? 1u : 0u;
-								dg_x2 += (inbn && win && !(zn >= m)) ? 1u : 0u;
-								dg_x3 += (inbn && win && zn >= m) ? 1u : 0u; // binade / boundary tests
-							}
+							diag.on_landing_refused(f, can && !ok, inbn,
+							                        (unsigned)(gxn - wx0) < (unsigned)wspan_x && (unsigned)(gyn - wy0) < (unsigned)wspan_y, zn >= m);
 							x = ok ? xn : x;
 							y = ok ? yn : y;
 							z = ok ? zn : z;
 							budget -= ok ? n : 0;
 						}
-						if (STATS && f.diag_mode == 4) {
-							const bool ie = inb0 && exact;
-							dg_x0 += (ie && !above) ? 1u : 0u;
-							dg_x1 += (ie && above && n < kMinLeap && z_bound) ? 1u : 0u;
-							dg_x2 += (ie && above && n < kMinLeap && !z_bound) ? 1u : 0u;
-							dg_x3 += (can && !ok) ? 1u : 0u;
-						}
-						if (STATS && f.diag_mode == 1 + 8) {
-							const bool sl = inb0 && exact && above && n < kMinLeap && !z_bound;
-							dg_x0 += (sl && lev == 0) ? 1u : 0u;
-							dg_x1 += (sl && lev == 1) ? 1u : 0u;
-							dg_x2 += (sl && lev == 2) ? 1u : 0u;
-							dg_x3 += (sl && lev >= 3) ? 1u : 0u;
-						}
-						if (STATS && f.diag_mode == 3 + 8) {
-							const bool bm = inb0 && exact && !above;
-							dg_x0 += (bm && lev == 0) ? 1u : 0u;
-							dg_x1 += (bm && lev == 1) ? 1u : 0u;
-							dg_x2 += (bm && lev == 2) ? 1u : 0u;
-							dg_x3 += (bm && lev == 3) ? 1u : 0u;
-						}
-						if (STATS && f.diag_mode == 5) {
-							dg_x0 += (lev == 0) ? 1u : 0u;
-							dg_x1 += (lev == 1) ? 1u : 0u;
-							dg_x2 += (lev == 2) ? 1u : 0u;
-							dg_x3 += (lev == 3) ? 1u : 0u;
-						}
-						if (STATS && f.diag_mode == 6) {
-							dg_x0 += (ok && lev == 0) ? 1u : 0u;
-							dg_x1 += (ok && lev == 1) ? 1u : 0u;
-							dg_x2 += (ok && lev == 2) ? 1u : 0u;
-							dg_x3 += (ok && lev == 3) ? 1u : 0u;
-						}
-						if (STATS && f.diag_mode == 7) {
-							dg_x0 += (ok && lev == 0) ? (unsigned)n : 0u;
-							dg_x1 += (ok && lev == 1) ? (unsigned)n : 0u;
-							dg_x2 += (ok && lev == 2) ? (unsigned)n : 0u;
-							dg_x3 += (ok && lev == 3) ? (unsigned)n : 0u;
-						}
-						if (STATS) {
-							dg_leaped += ok ? (unsigned)n : 0u;
-							dg_leaps += ok ? 1u : 0u;
-						}
+						diag.on_attempt_done(f, inb0, exact, above, n < kMinLeap, z_bound, can, ok, n, lev);
 						// level policy (performance only; any policy gives the same pixels):
 						//   window crossed                    -> coarser next time, if the height bound of this
 						//                                        level left room for a window kUpRatio times
@@ -352,54 +294,11 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						skip_group = skip_group || (ok && !binade_bound);
 					}
 				}
-				if (STATS && f.diag_mode == 12) { // wave-level view of the loop: who runs which block
-					const unsigned long long act = __ballot(true);
-					const unsigned long long att = __ballot(LEAP && dg_attempted);
-					const unsigned long long grp = __ballot(!skip_group);
-					if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
-						dg_x0 += 1u;
-						dg_x1 += att ? 1u : 0u;
-						dg_x2 += grp ? 1u : 0u;
-						dg_x3 += (unsigned)__popcll(act);
-					}
-				}
-				if (STATS && f.diag_mode == 14) { // attempt iterations by the share of active lanes that attempt
-					const unsigned long long act = __ballot(true);
-					const unsigned long long att = __ballot(LEAP && dg_attempted);
-					if (att && (int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
-						const int na = __popcll(att), nact = __popcll(act);
-						dg_x0 += (8 * na < nact) ? 1u : 0u;
-						dg_x1 += (8 * na >= nact && 4 * na < nact) ? 1u : 0u;
-						dg_x2 += (4 * na >= nact && 2 * na < nact) ? 1u : 0u;
-						dg_x3 += (2 * na >= nact) ? 1u : 0u;
-					}
-				}
-				if (STATS && f.diag_mode == 15) { // group iterations by the share of active lanes that march
-					const unsigned long long act = __ballot(true);
-					const unsigned long long grp = __ballot(!skip_group);
-					if (grp && (int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
-						const int ng = __popcll(grp), nact = __popcll(act);
-						dg_x0 += (8 * ng < nact) ? 1u : 0u;
-						dg_x1 += (8 * ng >= nact && 4 * ng < nact) ? 1u : 0u;
-						dg_x2 += (4 * ng >= nact && 2 * ng < nact) ? 1u : 0u;
-						dg_x3 += (2 * ng >= nact) ? 1u : 0u;
-					}
-				}
-				if (STATS && f.diag_mode == 13) { // lanes doing useful work in each block
-					const unsigned long long att = __ballot(LEAP && dg_attempted);
-					const unsigned long long grp = __ballot(!skip_group);
-					const unsigned long long act = __ballot(true);
-					if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
-						dg_x0 += att ? 64u : 0u;                    // lane slots spent in attempt blocks
-						dg_x1 += (unsigned)__popcll(att);           // ... of which useful
-						dg_x2 += grp ? 64u : 0u;                    // lane slots spent in group blocks
-						dg_x3 += (unsigned)__popcll(grp);           // ... of which useful
-					}
-				}
+				diag.on_trip(f, LEAP, skip_group);
 				if (skip_group) continue;
 
 				// --------------------------------------------- speculative group
-				if (STATS) ++dg_groups;
+				diag.on_group();
 				double X[kGroup], Y[kGroup], Z[kGroup], T[kGroup];
 				int cell[kGroup];
 				bool inb[kGroup];
@@ -516,30 +415,10 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 		else rgba = shade_miss(f, ray.dz);
 		out[(int64_t)pid.lrow * out_stride_px + pid.px] = rgba;
 		if (STATS && st.steps_per_pixel)
-			st.steps_per_pixel[(int64_t)pid.py * f.screen_w + pid.px] =
-			    f.diag_mode == 1 ? ((dg_attempts > 0xffffu ? 0xffffu : dg_attempts) << 16) |
-			                       (dg_groups > 0xffffu ? 0xffffu : dg_groups)
-			    : f.diag_mode == 2 ? (uint32_t)(__builtin_amdgcn_s_memtime() - t_start) // wave cycles
-			    : f.diag_mode == 3 ? (uint32_t)t_start
-			                 : (my_steps > 0xffffffffull ? 0xffffffffu : (uint32_t)my_steps);
+			st.steps_per_pixel[(int64_t)pid.py * f.screen_w + pid.px] = diag.pixel_value(f, my_steps);
 	}
 	publish_counters<STATS>(st, my_steps, my_hit, my_cap);
-	if (STATS) {
-		unsigned long long a = dg_attempts, l = dg_leaps, g = dg_groups, s = dg_leaped;
-		if (f.diag_mode >= 4) { a = dg_x0; l = dg_x1; g = dg_x2; s = dg_x3; }
-		for (int off = 32; off > 0; off >>= 1) {
-			a += __shfl_xor(a, off);
-			l += __shfl_xor(l, off);
-			g += __shfl_xor(g, off);
-			s += __shfl_xor(s, off);
-		}
-		if ((threadIdx.x & 63) == 0) {
-			if (a) atomicAdd(&st.counters[4], a);
-			if (l) atomicAdd(&st.counters[5], l);
-			if (g) atomicAdd(&st.counters[6], g);
-			if (s) atomicAdd(&st.counters[7], s);
-		}
-	}
+	diag.publish(st, f);
 }
 
 // ---------------------------------------------------------------- pyramid ----

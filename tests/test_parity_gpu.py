@@ -593,6 +593,7 @@ def test_two_streams_two_spherical_cameras(gpu, oracle):
     want = [oracle.render(oracle.make_cfg(c, params, 128, 128), heights, cmap)[0] for c in cams]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     bufs = [[torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(6)] for _ in range(2)]
+    torch.cuda.synchronize()  # (the fills ran on torch's current stream, the renders use their own)
     for rep in range(6):
         for i in (0, 1):
             # stream i alternates between the two cameras as well: slot reuse within one stream
@@ -633,9 +634,10 @@ def test_two_host_threads_share_one_scene(gpu, oracle):
             torch.cuda.set_device(0)
             gpu.set_device(0)
             stream = torch.cuda.Stream()
+            buf = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()  # (the fill ran on torch's current stream, the renders use `stream`)
             for rep in range(8):
                 for k in range(tid, 6, 2):
-                    buf = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
                     scene.render_rows_device(cams[k], buf.data_ptr(), W * 4, 0, H, stream=stream.cuda_stream)
                     stream.synchronize()
                     if not np.array_equal(buf.cpu().numpy(), want[k]):
