@@ -101,3 +101,27 @@ def test_scripts_compile():
     assert len(files) >= 15
     for f in files:
         py_compile.compile(f, doraise=True)
+
+
+def test_new_entry_points_validate_arguments_without_a_gpu(hmrm):
+    """Argument errors of the round-2 entry points are reported before any device is touched."""
+    import ctypes as C
+    from importlib import import_module
+    lib = import_module("heightmap-ray-marcher_amd.lib").lib
+    cam = hmrm.Camera.make(width=8, height=8)
+    bad = hmrm.Camera.make(width=0, height=8)
+    t = C.c_int32(123)
+    assert lib.hmrm_render_begin(None, C.byref(cam), C.byref(t)) == hmrm.HMRM_E_ARG
+    assert lib.hmrm_render_begin(None, C.byref(bad), C.byref(t)) == hmrm.HMRM_E_ARG and "resolution" in hmrm.last_error()
+    p = C.POINTER(C.c_uint8)()
+    assert lib.hmrm_render_wait(None, 0, C.byref(p), None) == hmrm.HMRM_E_ARG
+    lib.hmrm_render_release(None, 0)  # no-op
+    buf = (C.c_uint8 * 256)()
+    assert lib.hmrm_render_multi(None, 2, C.byref(cam), buf, 32) == hmrm.HMRM_E_ARG
+    assert lib.hmrm_record_orbit_multi(None, 1, C.byref(cam), 0.0, 0.0, 1.0, 0.0, 4, b"/tmp", 1, 1, 0) == hmrm.HMRM_E_ARG
+    n = C.c_uint64(7)
+    assert lib.hmrm_scene_take_capped(None, None, C.byref(n)) == hmrm.HMRM_E_ARG
+    assert lib.hmrm_debug_reload_env(None) == hmrm.HMRM_E_ARG
+    cam.sampling = 3
+    assert lib.hmrm_render_begin(None, C.byref(cam), C.byref(t)) == hmrm.HMRM_E_ARG and "sampling" in hmrm.last_error()
+    assert [hmrm.orbit_frame_owner(k, 3) for k in range(7)] == [0, 1, 2, 0, 1, 2, 0]
