@@ -14,6 +14,15 @@
  *
  * There is NO CPU fallback: entry points that render fail with HMRM_E_DEVICE
  * when no gfx950 device / HIP runtime is usable.
+ *
+ * Threading (the reference's loop is an OpenMP region over read-only globals, hmap.cpp:978): a scene may
+ * be used from several host threads.  Everything a launch mutates -- spherical tables, counters, the
+ * cache of per-frame records -- is kept per HIP stream, so hmrm_render_rows_device calls on different
+ * streams run concurrently on the device; the host-side set-up of a call is serialised per scene.  The
+ * entry points that return pixels in host memory (hmrm_render, _stats, _cycle, _multi) use the scene's own
+ * stream and scratch frame: one such call at a time per scene.  hmrm_render_begin may be called while
+ * other tickets are in flight.  hmrm_scene_update and hmrm_scene_destroy require that no launch of that
+ * scene is in flight on a caller's stream.  hmrm_last_error() is per thread.
  */
 #ifndef HMRM_H
 #define HMRM_H
