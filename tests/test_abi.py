@@ -125,3 +125,16 @@ def test_new_entry_points_validate_arguments_without_a_gpu(hmrm):
     cam.sampling = 3
     assert lib.hmrm_render_begin(None, C.byref(cam), C.byref(t)) == hmrm.HMRM_E_ARG and "sampling" in hmrm.last_error()
     assert [hmrm.orbit_frame_owner(k, 3) for k in range(7)] == [0, 1, 2, 0, 1, 2, 0]
+
+
+def test_header_is_c_and_links_from_a_c_program(hmrm, tmp_path):
+    """include/hmrm.h compiles as C99 and a plain C program can drive the library (tests/abi_smoke.c)."""
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(hmrm.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "abi_smoke.c"), "-L" + libdir, "-lhmrm", "-Wl,-rpath," + libdir, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stdout + r.stderr
