@@ -3,18 +3,19 @@
 # PMC passes (separate runs, counters only with --kernel-trace), A/B of the kernel variants and the
 # diagnostic tools.  Everything lands under gpurun_out/prof_<tag>/ ; summarise afterwards with
 #   python tools/pmc_summary.py gpurun_out/prof_<tag> C3 profiles/<tag>_C3_rocprof
-# usage: tools/profile_round.sh <tag> [quick]
+# usage: tools/profile_round.sh <tag> [quick]      (WL=C5 tools/profile_round.sh ... for another workload)
 set -u
 tag=${1:-round}
 quick=${2:-}
+WL=${WL:-C3}
 out=gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$out"; mkdir -p "$out"
-timeout -k 10 300 python bench.py > "$out/bench.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --no-cpu-baseline > "$out/bench_under_rocprof.log" 2>&1
+timeout -k 10 300 python bench.py --workload $WL > "$out/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --workload $WL --no-cpu-baseline > "$out/bench_under_rocprof.log" 2>&1
 pmc() { # <dir> <counters...>
 	d=$1; shift
-	rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/$d" -- python tools/prof_run.py C3 leap 10 > /dev/null 2>&1
+	rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/$d" -- python tools/prof_run.py $WL leap 10 > /dev/null 2>&1
 }
 pmc fetch FETCH_SIZE TCC_HIT_sum
 pmc write WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
