@@ -138,7 +138,10 @@ struct hmrm_scene {
 	bool bil_valid = false;
 	float *d_mipbuf_bil = nullptr; // the same over the 3x3-dilated table (bilinear quality mode)
 	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/16/64/256-cell windows every 2/8/32/128 cells
-	int32_t mip_w[hmrm::kMipLevels] = {}, mip_h[hmrm::kMipLevels] = {}, mip_off[hmrm::kMipLevels] = {};
+	int32_t mip_w[hmrm::kMipLevels] = {}, mip_h[hmrm::kMipLevels] = {};
+	int32_t mip_row = 0, mip_plane_shift = 0; // plane layout of both pyramids, see DevFrame
+	size_t mip_floats() const { return (size_t)(hmrm::kMipLevels + 1) << mip_plane_shift; }
+	float *plane(float *buf, int l) const { return buf + ((size_t)l << mip_plane_shift); }
 	hipStream_t stream = nullptr; // the scene's own stream (hmrm_render, updates)
 	hipStream_t copy_stream = nullptr; // device-to-host copies of the asynchronous ring
 	std::vector<RingFrame *> ring;
@@ -352,7 +355,8 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 			++fr.min_level;
 		fr.mipbuf = s->d_mipbuf;
 		fr.mipbuf_bil = s->d_mipbuf_bil;
-		for (int l = 0; l < hmrm::kMipLevels; ++l) fr.mip_off[l] = s->mip_off[l];
+		fr.mip_row = s->mip_row;
+		fr.mip_plane_shift = s->mip_plane_shift;
 		slot->cam = *cam;
 		slot->params = s->params;
 		slot->thr_max_bits = thr_bits;
@@ -376,7 +380,11 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const Fra
                  uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats) {
 	hmrm::RowMap rows_in_order = rows;
 	rows_in_order.tile_rot = choose_tile_rot(s, slot->row_cost, rows);
-	if (s->knobs.kernel == 2 && f.sampling == 0) { // (the literal loop only knows the reference's sampling)
+	// the production kernel indexes cells and windows with 24-bit multiplies (leap_common.hpp index_2d): a map
+	// with a side of 2^24 cells or more (then at most 32 cells the other way) goes through the literal loop
+	const bool huge_side = s->map_w >= (1 << 24) || s->map_h >= (1 << 24);
+	if (huge_side && f.sampling != 0) return fail(HMRM_E_ARG, "maps with a side of 2^24 cells or more support nearest sampling only");
+	if ((s->knobs.kernel == 2 || huge_side) && f.sampling == 0) { // (the literal loop only knows the reference's sampling)
 		HIP_TRY(hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters, d_steps,
 		                            d_entry, stats, c->stream));
 		return HMRM_OK;
@@ -415,28 +423,36 @@ int ensure_stats(hmrm_scene *s, size_t px) {
 int ensure_bilinear_pyramid(hmrm_scene *s) {
 	if (s->bil_valid) return HMRM_OK;
 	const int64_t n = (int64_t)s->map_w * s->map_h;
+	if (!s->d_mipbuf_bil) HIP_TRY(hipMalloc((void **)&s->d_mipbuf_bil, s->mip_floats() * sizeof(float)));
 	double *tmp = nullptr;
 	HIP_TRY(hipMalloc((void **)&tmp, (size_t)n * sizeof(double)));
 	hipError_t e = hmrm::launch_dilate3x3(s->d_thr, s->map_w, s->map_h, tmp, s->stream);
 	if (e == hipSuccess)
-		e = hmrm::launch_build_mip0(tmp, s->map_w, s->map_h, s->d_mipbuf_bil + s->mip_off[0], s->mip_w[0],
-		                            s->mip_h[0], s->stream);
+		e = hmrm::launch_build_mip0(tmp, s->map_w, s->map_h, s->plane(s->d_mipbuf_bil, 0), s->mip_w[0], s->mip_h[0],
+		                            s->mip_row, s->stream);
 	for (int l = 1; l < hmrm::kMipLevels && e == hipSuccess; ++l)
-		e = hmrm::launch_build_mip_up(s->d_mipbuf_bil + s->mip_off[l - 1], s->mip_w[l - 1], s->mip_h[l - 1],
-		                              s->d_mipbuf_bil + s->mip_off[l], s->mip_w[l], s->mip_h[l], s->stream);
+		e = hmrm::launch_build_mip_up(s->plane(s->d_mipbuf_bil, l - 1), s->mip_w[l - 1], s->mip_h[l - 1],
+		                              s->plane(s->d_mipbuf_bil, l), s->mip_w[l], s->mip_h[l], s->mip_row, s->stream);
 	// whole-map bound = max over the coarsest level (its windows cover every cell)
 	const int top = hmrm::kMipLevels - 1;
-	std::vector<float> coarse((size_t)s->mip_w[top] * s->mip_h[top]);
+	const size_t top_span = (size_t)hmrm::mip_index(s->mip_w[top] - 1, s->mip_h[top] - 1, s->mip_row) + 1;
+	std::vector<float> coarse(top_span);
 	if (e == hipSuccess)
-		e = hipMemcpyAsync(coarse.data(), s->d_mipbuf_bil + s->mip_off[top], coarse.size() * sizeof(float),
-		                   hipMemcpyDeviceToHost, s->stream);
+		e = hipMemcpyAsync(coarse.data(), s->plane(s->d_mipbuf_bil, top), top_span * sizeof(float), hipMemcpyDeviceToHost, s->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
 	(void)hipFree(tmp);
 	if (e != hipSuccess) return fail(HMRM_E_DEVICE, std::string("bilinear pyramid: ") + hipGetErrorString(e));
-	double m = -__builtin_huge_val();
-	for (float v : coarse)
-		if ((double)v > m) m = (double)v;
-	s->thr_max_bil = m;
+	float m = -__builtin_huge_valf();
+	for (int iy = 0; iy < s->mip_h[top]; ++iy)
+		for (int ix = 0; ix < s->mip_w[top]; ++ix) {
+			const float v = coarse[hmrm::mip_index(ix, iy, s->mip_row)];
+			if (v > m) m = v;
+		}
+	// (pageable source: the copy is staged before the call returns)
+	e = hipMemcpyAsync(s->plane(s->d_mipbuf_bil, hmrm::kMipLevels), &m, sizeof m, hipMemcpyHostToDevice, s->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+	if (e != hipSuccess) return fail(HMRM_E_DEVICE, std::string("bilinear pyramid: ") + hipGetErrorString(e));
+	s->thr_max_bil = (double)m;
 	s->bil_valid = true;
 	return HMRM_OK;
 }
@@ -451,11 +467,11 @@ int run_update_heights(hmrm_scene *s) {
 	                                     s->params.lum_b, s->params.min_height, s->params.max_height,
 	                                     false, s->d_maxkey, s->stream));
 	// window-maximum pyramid for the exact-leap traversal (render_fast.hip)
-	HIP_TRY(hmrm::launch_build_mip0(s->d_thr, s->map_w, s->map_h, s->d_mipbuf + s->mip_off[0], s->mip_w[0],
-	                                s->mip_h[0], s->stream));
+	HIP_TRY(hmrm::launch_build_mip0(s->d_thr, s->map_w, s->map_h, s->plane(s->d_mipbuf, 0), s->mip_w[0], s->mip_h[0],
+	                                s->mip_row, s->stream));
 	for (int l = 1; l < hmrm::kMipLevels; ++l)
-		HIP_TRY(hmrm::launch_build_mip_up(s->d_mipbuf + s->mip_off[l - 1], s->mip_w[l - 1], s->mip_h[l - 1],
-		                                  s->d_mipbuf + s->mip_off[l], s->mip_w[l], s->mip_h[l], s->stream));
+		HIP_TRY(hmrm::launch_build_mip_up(s->plane(s->d_mipbuf, l - 1), s->mip_w[l - 1], s->mip_h[l - 1],
+		                                  s->plane(s->d_mipbuf, l), s->mip_w[l], s->mip_h[l], s->mip_row, s->stream));
 	s->bil_valid = false; // rebuilt by the next bilinear frame
 	s->thr32_valid = false;
 	for (StreamCtx *c : s->ctxs)
@@ -464,6 +480,10 @@ int run_update_heights(hmrm_scene *s) {
 	HIP_TRY(hipMemcpyAsync(&key, s->d_maxkey, sizeof key, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->thr_max = key ? hmrm::max_key_to_double(key) : -__builtin_huge_val();
+	// the top plane's one element: the whole-map bound, rounded like the windows
+	const float top = hmrm::round_up_to_float_host(s->thr_max);
+	HIP_TRY(hipMemcpyAsync(s->plane(s->d_mipbuf, hmrm::kMipLevels), &top, sizeof top, hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
 	return HMRM_OK;
 }
 
@@ -531,14 +551,13 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 			const int stride = 1 << hmrm::mip_stride_shift(l); // windows of 2*stride cells every stride cells
 			s->mip_w[l] = (map_w + stride - 1) / stride;
 			s->mip_h[l] = (map_h + stride - 1) / stride;
-			s->mip_off[l] = l == 0 ? 0 : s->mip_off[l - 1] + s->mip_w[l - 1] * s->mip_h[l - 1];
 		}
-		{
-			const int last = hmrm::kMipLevels - 1;
-			const size_t total = (size_t)s->mip_off[last] + (size_t)s->mip_w[last] * s->mip_h[last];
-			HIP_TRY(hipMalloc((void **)&s->d_mipbuf, total * sizeof(float)));
-			HIP_TRY(hipMalloc((void **)&s->d_mipbuf_bil, total * sizeof(float)));
-		}
+		// every plane has level 0's row pitch and a power-of-two plane pitch (DevFrame); the pyramid of the
+		// bilinear mode is allocated by its first frame
+		s->mip_row = s->mip_w[0];
+		while (((size_t)1 << s->mip_plane_shift) < (size_t)hmrm::mip_index(s->mip_w[0] - 1, s->mip_h[0] - 1, s->mip_row) + 1)
+			++s->mip_plane_shift;
+		HIP_TRY(hipMalloc((void **)&s->d_mipbuf, s->mip_floats() * sizeof(float)));
 		HIP_TRY(hipMalloc((void **)&s->d_maxkey, sizeof(unsigned long long)));
 		HIP_TRY(hipMemcpyAsync(s->d_rgb, height_rgb, n * 3, hipMemcpyHostToDevice, s->stream));
 		HIP_TRY(hipMemcpyAsync(s->d_cmap, color_rgba, n * 4, hipMemcpyHostToDevice, s->stream));

@@ -41,11 +41,16 @@ struct DevFrame {
 	int64_t step_cap;            // guard for the reference's unbounded while(true) (:1000)
 	// window-maximum pyramid over the thr table (render_fast.hip): level l holds the maximum
 	// of thr (NaN ignored: z < NaN never hits) over S x S-cell windows, S = 4, 16, 64, 256,
-	// placed every S/2 cells; floats rounded up.  All levels live in one buffer: level l starts
-	// at mip_off[l] and has ceil(map_w / (S/2)) windows per row.
+	// placed every S/2 cells; floats rounded up.  One buffer of kMipLevels + 1 planes of
+	// 1 << mip_plane_shift floats: window (ix, iy) of level l is element
+	// (l << mip_plane_shift) + iy * mip_row + ix -- every level uses level 0's row pitch, so the
+	// kernel needs no per-level table -- and plane kMipLevels holds one element, the whole-map
+	// bound (thr_max rounded up).
 	const float *mipbuf;
 	const float *mipbuf_bil;     // the same pyramid over the 3x3-dilated table (bilinear quality mode)
-	int32_t mip_off[8];
+	int32_t mip_row;             // row pitch of every plane (windows per row of level 0)
+	int32_t mip_plane_shift;     // log2 of the plane pitch
+	int32_t pad_mip_[6];
 	int32_t diag_mode;           // tools only: what the instrumented kernel writes per pixel
 	int32_t sampling;            // 0 nearest cell (the reference), 1 bilinear quality mode, 2 nearest cell with float thresholds
 	int32_t min_level;           // finest pyramid level worth an attempt (api.cpp, from min_window)
@@ -60,8 +65,17 @@ struct DevFrame {
 #define HMRM_LEVEL_STEP 2
 #endif
 constexpr int kLevelStep = HMRM_LEVEL_STEP;
-constexpr int kMipLevels = kLevelStep == 2 ? 4 : 7;
+#ifndef HMRM_MIP_LEVELS
+#define HMRM_MIP_LEVELS (HMRM_LEVEL_STEP == 2 ? 4 : 7)
+#endif
+constexpr int kMipLevels = HMRM_MIP_LEVELS;
 constexpr int mip_stride_shift(int l) { return 1 + kLevelStep * l; } // log2(S/2)
+// Element of window (ix, iy) inside a plane (row-major with level 0's pitch; 8 x 4-window tiles per
+// 128-byte line were tried and change nothing, profiles/r02_experiments.txt).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned mip_index(int ix, int iy, int pitch) { return (unsigned)(iy * pitch + ix); }
 
 // Which framebuffer rows a launch covers and where they land in the output.
 struct RowMap {

@@ -44,6 +44,20 @@ __device__ __forceinline__ int cvt_i32_sat(double q) {
 	asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(q));
 	return r;
 }
+// (int)(-q): the negation rides on the instruction's source modifier (exact, like the reference's
+// unary minus before the cast, hmap.cpp:1003)
+__device__ __forceinline__ int cvt_i32_sat_neg(double q) {
+	int r;
+	asm("v_cvt_i32_f64_e64 %0, -%1" : "=v"(r) : "v"(q));
+	return r;
+}
+// row * width + col for 0 <= row, col, width < 2^24 with the product below 2^32 (cell and window
+// indices of a map: api.cpp refuses larger dimensions for this kernel): one full-rate v_mad_u32_u24
+// instead of the quarter-rate 32-bit multiply.  Garbage in, garbage out for lanes outside the grid
+// (their index is replaced by 0 before use).
+__device__ __forceinline__ int index_2d(int row, int width, int col) {
+	return (int)(__umul24((unsigned)row, (unsigned)width) + (unsigned)col);
+}
 
 // Exact-stepping state of one coordinate inside its current binade.
 struct Axis {

@@ -19,6 +19,9 @@ struct LoopDiag<false> {
 	__device__ __forceinline__ void on_attempt_done(const DevFrame &, bool, bool, bool, bool, bool, bool, bool, int, int) {}
 	__device__ __forceinline__ void on_trip(const DevFrame &, bool, bool) {}
 	__device__ __forceinline__ void on_group() {}
+	__device__ __forceinline__ void load_begin(const DevFrame &, int) {}
+	__device__ __forceinline__ void load_end(const DevFrame &, int, float &) {}
+	__device__ __forceinline__ void load_end(const DevFrame &, int, double &, double &, double &, double &) {}
 	__device__ __forceinline__ uint32_t pixel_value(const DevFrame &, unsigned long long) { return 0u; }
 	__device__ __forceinline__ void publish(const StatsOut &, const DevFrame &) {}
 };
@@ -28,7 +31,7 @@ struct LoopDiag<true> {
 	uint32_t attempts = 0, leaps = 0, groups = 0;
 	unsigned long long leaped = 0;
 	unsigned long long x0 = 0, x1 = 0, x2 = 0, x3 = 0; // meaning depends on diag_mode
-	unsigned long long t_start = 0;
+	unsigned long long t_start = 0, t_load = 0;
 	bool attempted = false; // this trip ran the attempt block
 
 	__device__ __forceinline__ void start() { t_start = __builtin_amdgcn_s_memtime(); }
@@ -115,11 +118,27 @@ struct LoopDiag<true> {
 		}
 	}
 	__device__ __forceinline__ void on_group() { ++groups; }
+	// modes 17 (pyramid look-up) / 18 (the group's height loads): cycles a wave waits for the data, per pixel
+	// (the wait is forced right after the load: the instrumented kernel then overlaps nothing with it)
+	__device__ __forceinline__ void load_begin(const DevFrame &f, int mode) {
+		if (f.diag_mode == mode) t_load = __builtin_amdgcn_s_memtime();
+	}
+	__device__ __forceinline__ void load_end(const DevFrame &f, int mode, float &v) {
+		if (f.diag_mode != mode) return;
+		asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
+		x0 += __builtin_amdgcn_s_memtime() - t_load;
+	}
+	__device__ __forceinline__ void load_end(const DevFrame &f, int mode, double &a, double &b, double &c, double &d) {
+		if (f.diag_mode != mode) return;
+		asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+		x0 += __builtin_amdgcn_s_memtime() - t_load;
+	}
 	// what the per-pixel output holds instead of the step count (modes 1-3)
 	__device__ __forceinline__ uint32_t pixel_value(const DevFrame &f, unsigned long long steps) {
 		if (f.diag_mode == 1) return ((attempts > 0xffffu ? 0xffffu : attempts) << 16) | (groups > 0xffffu ? 0xffffu : groups);
 		if (f.diag_mode == 2) return (uint32_t)(__builtin_amdgcn_s_memtime() - t_start); // wave cycles
 		if (f.diag_mode == 3) return (uint32_t)t_start;
+		if (f.diag_mode == 17 || f.diag_mode == 18) return (uint32_t)x0;
 		return steps > 0xffffffffull ? 0xffffffffu : (uint32_t)steps;
 	}
 	__device__ __forceinline__ void publish(const StatsOut &st, const DevFrame &f) {

@@ -35,10 +35,13 @@ hipError_t launch_thr_to_float(const double *d_thr, float *d_thr32, int64_t n, h
 // 3x3 maximum filter of the thr table (bounds every bilinear interpolation, render_fast.hip).
 hipError_t launch_dilate3x3(const double *d_thr, int w, int h, double *d_dst, hipStream_t stream);
 // Window-maximum pyramid (see render_fast.hip): level 0 from the thr table, level l+1 from level l.
+// `pitch` = row pitch (floats) of every plane of the pyramid buffer (DevFrame::mip_row).
 hipError_t launch_build_mip0(const double *d_thr, int map_w, int map_h, float *d_dst, int dst_w, int dst_h,
-                             hipStream_t stream);
+                             int pitch, hipStream_t stream);
 hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *d_dst, int dst_w, int dst_h,
-                               hipStream_t stream);
+                               int pitch, hipStream_t stream);
+// round-up-to-float of a double (the pyramid's rounding), on the host: for the whole-map element
+float round_up_to_float_host(double v);
 
 // Pixel tile (= workgroup) shape of launch_render / launch_render_fast.
 void render_tile_shape(int *tile_w, int *tile_h);

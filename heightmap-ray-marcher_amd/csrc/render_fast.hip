@@ -106,7 +106,7 @@ __device__ __forceinline__ uint32_t shade_hit_bilinear(const DevFrame &f, const 
 #define HMRM_MIN_WAVES 1
 #endif
 #ifdef HMRM_WAVES_PER_EU
-#define HMRM_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(HMRM_WAVES_PER_EU, HMRM_WAVES_PER_EU)))
+#define HMRM_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(HMRM_WAVES_PER_EU, HMRM_WAVES_PER_EU), amdgpu_num_vgpr(512 / HMRM_WAVES_PER_EU / 8 * 8)))
 #else
 #define HMRM_OCCUPANCY_ATTR
 #endif
@@ -196,24 +196,25 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						bool near0 = false;
 						double qx = cell_coord_fast<GWM>(x, f, near0), qy = cell_coord_fast<GWM>(-y, f, near0);
 						if (GWM == 2 && near0) { qx = x / f.grid_width; qy = -y / f.grid_width; }
-						const int gx = cvt_i32_sat(qx), gy = cvt_i32_sat(qy);
+						const int gx = cvt_i32_sat(qx), gy = GWM == 0 ? cvt_i32_sat_neg(y) : cvt_i32_sat(qy);
 						const bool inb0 = (unsigned)gx < wlim && (unsigned)gy < hlim;
 						const bool exact = ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
 						const bool top = lev == kTopLevel;
-						// window (ix,iy) of level lev: S = 2<<hs cells wide, every 1<<hs cells
-						const int hs = kLevelStep * lev + 1;
+						// window (ix,iy) of level lev: S = 2<<hs cells wide, every 1<<hs cells.  The whole map is
+						// the one window of the top plane: with hs = 29 every in-grid cell has ix = iy = 0 and the
+						// spans below come out as the map's, so nothing else treats that level specially.
+						const int hs = top ? 29 : kLevelStep * lev + 1;
 						int ix = (gx >> hs) - offx, iy = (gy >> hs) - offy;
 						ix = ix < 0 ? 0 : ix;
 						iy = iy < 0 ? 0 : iy;
-						const int mw = (f.map_w + (1 << hs) - 1) >> hs; // windows per row (as built on the host)
-						int loff = 0;
-#pragma unroll
-						for (int l = 1; l < kMipLevels; ++l) loff = lev == l ? f.mip_off[l] : loff;
-						const float mf = (BILINEAR ? f.mipbuf_bil : f.mipbuf)[(top || !inb0) ? 0 : loff + iy * mw + ix];
-						const double m = top ? f.thr_max : (double)mf; // (thr_max also bounds every interpolated threshold)
-						const int wx0 = top ? 0 : ix << hs, wy0 = top ? 0 : iy << hs;
+						const unsigned widx = ((unsigned)lev << f.mip_plane_shift) + (unsigned)index_2d(iy, f.mip_row, ix); // (= mip_index)
+						diag.load_begin(f, 17);
+						float mf = (BILINEAR ? f.mipbuf_bil : f.mipbuf)[inb0 ? widx : 0u];
+						diag.load_end(f, 17, mf);
+						const double m = (double)mf; // (floats rounded up: also bounds every float / interpolated threshold)
+						const int wx0 = ix << hs, wy0 = iy << hs;
 						// (the last windows of a row / column hang over the map's edge: the usable span ends at the edge)
-						const int wspan_x = top ? f.map_w : min(2 << hs, f.map_w - wx0), wspan_y = top ? f.map_h : min(2 << hs, f.map_h - wy0);
+						const int wspan_x = min(2 << hs, f.map_w - wx0), wspan_y = min(2 << hs, f.map_h - wy0);
 						const bool above = z >= m;
 						// Nothing below can succeed unless the ray is above this window's maximum: when no
 						// lane of the wave is, skip the estimate and the verification (the usual case in
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							bool nearn = false;
 							double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
 							if (GWM == 2 && nearn) { qxn = xn / f.grid_width; qyn = -yn / f.grid_width; }
-							const int gxn = cvt_i32_sat(qxn), gyn = cvt_i32_sat(qyn);
+							const int gxn = cvt_i32_sat(qxn), gyn = GWM == 0 ? cvt_i32_sat_neg(yn) : cvt_i32_sat(qyn);
 							const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim;
 							ok = can && inbn && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
 							     (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
@@ -283,15 +284,16 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						const bool crossed = ok && !z_bound;
 						const bool hl = !crossed && height_limited;
 						const bool other = !crossed && !hl;
-						const bool go_up = crossed ? (room_z >= kUpRatio * room && !binade_bound) : other;
+						// (lane-mask logic: `a ? b : c` on booleans would be materialised in VGPRs)
+						const bool go_up = (crossed & (room_z >= kUpRatio * room) & !binade_bound) | other;
 						const int fails_before = fails;
 						lev = hl ? finer : (go_up ? coarser : lev);
-						fails = (crossed || (hl && ok)) ? 0 : (other ? fails + 1 : fails);
-						cooldown = hl ? ((!ok && at_finest) ? f.finest_pause : 0) : (other ? (fails_before < 3 ? fails_before : 3) : 0);
-						skip_group = hl && !ok && !at_finest; // retry one level down without marching
-						// after a jump look at the next window straight away -- unless the jump stopped at a
-						// binade boundary: only real steps cross it, another attempt here would just fail
-						skip_group = skip_group || (ok && !binade_bound);
+						fails = (crossed | (hl & ok)) ? 0 : fails + (other ? 1 : 0);
+						cooldown = (hl & !ok & at_finest) ? f.finest_pause : (other ? (fails_before < 3 ? fails_before : 3) : 0);
+						// retry one level down without marching; after a jump look at the next window straight
+						// away -- unless the jump stopped at a binade boundary: only real steps cross it,
+						// another attempt here would just fail
+						skip_group = (hl & !ok & !at_finest) | (ok & !binade_bound);
 					}
 				}
 				diag.on_trip(f, LEAP, skip_group);
@@ -326,10 +328,11 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 #pragma unroll
 				for (int j = 0; j < kGroup; ++j) {
 					const double qx = QX[j], qy = QY[j];
-					const int gx = cvt_i32_sat(qx), gy = cvt_i32_sat(qy); // hmap.cpp:1001-1004
+					const int gx = cvt_i32_sat(qx), gy = GWM == 0 ? cvt_i32_sat_neg(Y[j]) : cvt_i32_sat(qy); // hmap.cpp:1001-1004
 					inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;      // hmap.cpp:1006-1011
-					cell[j] = inb[j] ? gy * f.map_w + gx : 0;
+					cell[j] = inb[j] ? index_2d(gy, f.map_w, gx) : 0;
 				}
+				diag.load_begin(f, 18);
 				if (BILINEAR) {
 #pragma unroll
 					for (int j = 0; j < kGroup; ++j) {
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 #pragma unroll
 					for (int j = 0; j < kGroup; ++j) T[j] = F32 ? (double)thr32[cell[j]] : thr[cell[j]]; // hmap.cpp:1013-1014 (+ c0.z)
 				}
+				if (kGroup == 4) diag.load_end(f, 18, T[0], T[1], T[2], T[3]);
 				if (budget >= kGroup) {
 					// in order: the first position that leaves the grid (:1006) or hits (:1016) ends the ray
 					int first = kGroup, hit_cell = 0, hit_j = 0;
@@ -422,21 +426,23 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 }
 
 // ---------------------------------------------------------------- pyramid ----
-__device__ __forceinline__ float round_up_to_float(double v) {
+__host__ __device__ __forceinline__ float round_up_to_float(double v) {
 	float r = (float)v;
 	if ((double)r < v) { // conversion rounded down (v finite): next float towards +inf
-		uint32_t b = __float_as_uint(r);
+		uint32_t b;
+		__builtin_memcpy(&b, &r, sizeof b);
 		if (r == 0.0f) b = 1u;                 // smallest positive subnormal
 		else if (b & 0x80000000u) b -= 1u;     // negative: magnitude shrinks
 		else b += 1u;                          // positive: magnitude grows (max float -> +inf)
-		r = __uint_as_float(b);
+		__builtin_memcpy(&r, &b, sizeof r);
 	}
 	return r;
 }
+float round_up_to_float_host(double v) { return round_up_to_float(v); }
 
 // Level 0: window (ix,iy) = max of thr over cells [2ix, 2ix+4) x [2iy, 2iy+4), clipped; NaN ignored.
 __global__ __launch_bounds__(256) void k_build_mip0(const double *__restrict__ thr, int map_w, int map_h,
-                                                    float *__restrict__ dst, int dst_w, int dst_h) {
+                                                    float *__restrict__ dst, int dst_w, int dst_h, int pitch) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (int64_t)dst_w * dst_h) return;
 	const int ix = (int)(i % dst_w), iy = (int)(i / dst_w);
@@ -446,13 +452,13 @@ __global__ __launch_bounds__(256) void k_build_mip0(const double *__restrict__ t
 			const double v = thr[(int64_t)yy * map_w + xx];
 			if (v > m) m = v;
 		}
-	dst[i] = round_up_to_float(m);
+	dst[mip_index(ix, iy, pitch)] = round_up_to_float(m);
 }
 
 // Level l+1 from level l (H = stride of level l, windows 2H wide): with F = 2^kLevelStep the window
 // of 2FH cells at cell FH*i is the union of the level-l windows with indices F*i + {0, 2, .., 2(F-1)}.
 __global__ __launch_bounds__(256) void k_build_mip_up(const float *__restrict__ src, int src_w, int src_h,
-                                                      float *__restrict__ dst, int dst_w, int dst_h) {
+                                                      float *__restrict__ dst, int dst_w, int dst_h, int pitch) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (int64_t)dst_w * dst_h) return;
 	const int ix = (int)(i % dst_w), iy = (int)(i / dst_w);
@@ -464,11 +470,11 @@ __global__ __launch_bounds__(256) void k_build_mip_up(const float *__restrict__ 
 		for (int a = 0; a < F; ++a) {
 			const int xx = F * ix + 2 * a;
 			if (xx >= src_w) break;
-			const float v = src[(int64_t)yy * src_w + xx];
+			const float v = src[mip_index(xx, yy, pitch)];
 			if (v > m) m = v;
 		}
 	}
-	dst[i] = m;
+	dst[mip_index(ix, iy, pitch)] = m;
 }
 
 // 3x3 maximum filter of the thr table (edges clamped, NaN ignored) plus a rounding margin:
@@ -499,18 +505,18 @@ hipError_t launch_dilate3x3(const double *d_thr, int w, int h, double *d_dst, hi
 }
 
 hipError_t launch_build_mip0(const double *d_thr, int map_w, int map_h, float *d_dst, int dst_w, int dst_h,
-                             hipStream_t stream) {
+                             int pitch, hipStream_t stream) {
 	const int64_t n = (int64_t)dst_w * dst_h;
 	hipLaunchKernelGGL(k_build_mip0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_thr, map_w,
-	                   map_h, d_dst, dst_w, dst_h);
+	                   map_h, d_dst, dst_w, dst_h, pitch);
 	return hipGetLastError();
 }
 
 hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *d_dst, int dst_w, int dst_h,
-                               hipStream_t stream) {
+                               int pitch, hipStream_t stream) {
 	const int64_t n = (int64_t)dst_w * dst_h;
 	hipLaunchKernelGGL(k_build_mip_up, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_src, src_w,
-	                   src_h, d_dst, dst_w, dst_h);
+	                   src_h, d_dst, dst_w, dst_h, pitch);
 	return hipGetLastError();
 }
 

@@ -29,3 +29,14 @@ span = (wt0.max() - wt0.min()) & 0xffffffff
 print("start-time span (cycles, mod 2^32):", span, " latest start + its duration vs earliest start:", int(((wt0 - wt0.min()) + wcyc).max()))
 i = np.unravel_index(np.argmax((wt0 - wt0.min()) + wcyc), wcyc.shape)
 print(" last-finishing wave: tile", i, "iterations", int(wit[i]), "cycles", int(wcyc[i]), "start offset", int(wt0[i] - wt0.min()))
+# where the heaviest waves' time goes: cycles waiting for the pyramid look-up (mode 17) and for the group's
+# height loads (mode 18), each forced to complete right after its issue (so nothing overlaps it)
+wl17, wl18 = waves(diag(17).astype(np.int64), np.max), waves(diag(18).astype(np.int64), np.max)
+cyc17, cyc18 = waves(cyc, np.max), None
+order = np.argsort(wcyc, axis=None)[::-1][:8]
+print("heaviest waves: iterations, cycles (plain run), pyramid-load wait, group-load wait (instrumented runs)")
+for o in order:
+    i = np.unravel_index(o, wcyc.shape)
+    print(f"  tile {i}: iterations {int(wit[i]):4d}  cycles {int(wcyc[i]):8d}  pyramid wait {int(wl17[i]):8d}  group wait {int(wl18[i]):8d}")
+m = wit >= 32
+print("waves with >= 32 iterations: cycles %.3e  pyramid wait %.3e  group wait %.3e" % (wcyc[m].sum(), wl17[m].sum(), wl18[m].sum()))
