@@ -43,8 +43,19 @@ def short(name):
     return name.split("(")[0].replace("void hmrm::", "")
 
 
+def newest_per_dir(pattern):
+    """gpurun merges a call's output INTO the local copy of the directory: a tag used twice leaves the older run's
+    files (other pids) beside the new ones.  One rocprofv3 pass writes one file of a kind per directory: keep the newest."""
+    best = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True):
+for f in newest_per_dir(os.path.join(root, "**", "*_counter_collection.csv")):
     per_dispatch = collections.defaultdict(float)
     names = {}
     for r in csv.DictReader(open(f)):
@@ -55,7 +66,7 @@ for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursi
         per_kernel[names[disp]][cname].append(v)
 
 durations = collections.defaultdict(list)
-for f in glob.glob(os.path.join(root, "trace", "**", "*_kernel_trace.csv"), recursive=True):
+for f in newest_per_dir(os.path.join(root, "trace", "**", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
         if product_kernel(r["Kernel_Name"]):
             durations[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -116,7 +127,7 @@ if frame_ns and "valu" in entry:
                  + (f", weighted {entry['valu']['busy_cycles_weighted'] / simd_cycles:.3f}"
                     if entry['valu'].get('busy_cycles_weighted') else ""))
 
-stats = [open(f).read() for f in glob.glob(os.path.join(root, "**", "*_kernel_stats.csv"), recursive=True)]
+stats = [open(f).read() for f in newest_per_dir(os.path.join(root, "**", "*_kernel_stats.csv"))]
 text = "\n".join(lines) + "\n\n" + "\n".join(stats)
 open(out_prefix + ".txt", "w").write(text)
 print(text)
