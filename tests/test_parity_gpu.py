@@ -1048,3 +1048,28 @@ def test_very_tall_frame_uses_the_third_grid_dimension(gpu, oracle):
     assert st.rays == cam.width * cam.height and st.steps == total
     assert np.array_equal(fb, ofb) and np.array_equal(scene.render(cam), ofb)
     scene.close()
+
+
+def test_map_with_a_side_of_2_pow_24_cells(gpu, oracle):
+    """The production kernel indexes cells with 24-bit multiplies; a strip map 2^24 cells long (the longest side the
+    reference's image loader accepts) is routed through the literal kernel and still matches the oracle; the
+    additive sampling modes refuse it by name."""
+    w, h = 1 << 24, 1
+    rng = np.random.RandomState(5)
+    rgb = rng.randint(0, 256, size=(h, w, 3), dtype=np.uint8)
+    cmap = rng.randint(0, 256, size=(h, w, 4), dtype=np.uint8)
+    cmap[..., 3] = 255
+    params = gpu.SceneParams.make(0.0, 6.0, grid_width=1.0)
+    cam = gpu.Camera.make(width=24, height=16, projection=1, hfov=gpu.degrees_to_rads(20), hang=0.0,
+                          vang=gpu.degrees_to_rads(172), pos=(16000000.25, -0.5, 14.0), step_dist=0.25, bg=(9, 8, 7))
+    heights = oracle.update_heightmap(rgb, params)
+    ofb, total, capped, *_ = oracle.render(oracle.make_cfg(cam, params, w, h), heights, cmap)
+    assert capped == 0 and total > 0
+    scene = gpu.Scene(rgb, cmap, params)
+    fb, st, *_ = scene.render_stats(cam)
+    assert np.array_equal(fb, ofb) and st.steps == total and st.hits > 0
+    assert st.leap_attempts == 0  # (the literal loop ran)
+    with pytest.raises(gpu.HmrmError) as e:
+        scene.render(_bilinear(cam))
+    assert e.value.code == gpu.HMRM_E_ARG and "2^24" in str(e.value)
+    scene.close()
