@@ -344,11 +344,9 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 			HIP_TRY(hipStreamSynchronize(s->stream));
 			s->thr32_valid = true;
 		}
-		// whole-map bound of the thresholds the kernel compares with: a float threshold is at most the
-		// double maximum rounded UP to float (the pyramid's window maxima are rounded up already)
-		fr.thr_max = cam->sampling == HMRM_BILINEAR ? s->thr_max_bil
-		             : cam->sampling == HMRM_NEAREST_F32 ? (double)std::nextafterf((float)s->thr_max, HUGE_VALF)
-		                                                 : s->thr_max;
+		// (informational: the kernel reads the whole-map bound from the pyramid's top plane, rounded up to
+		// float like every window maximum -- which also bounds the float copy of a threshold)
+		fr.thr_max = cam->sampling == HMRM_BILINEAR ? s->thr_max_bil : s->thr_max;
 		// the finest level whose windows have at least min_window cells (camera.cpp's hint)
 		fr.min_level = 0;
 		while (fr.min_level < hmrm::kMipLevels - 1 && (2 << hmrm::mip_stride_shift(fr.min_level)) < fr.min_window)

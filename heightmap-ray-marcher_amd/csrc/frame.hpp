@@ -37,7 +37,7 @@ struct DevFrame {
 	double inv_grid_width;       // fl(1/grid_width); exact iff grid_pow2 != 0
 	int32_t grid_pow2;           // grid_width is a normal power of two: x/gw == x*(1/gw) exactly
 	int32_t grid_mode;           // 0: grid_width == 1.0, 1: power of two, 2: general
-	double thr_max;              // max over cells of heightmap_buf[i] + c0.z
+	double thr_max;              // max over cells of heightmap_buf[i] + c0.z (informational; the kernel uses the pyramid's top plane)
 	int64_t step_cap;            // guard for the reference's unbounded while(true) (:1000)
 	// window-maximum pyramid over the thr table (render_fast.hip): level l holds the maximum
 	// of thr (NaN ignored: z < NaN never hits) over S x S-cell windows, S = 4, 16, 64, 256,

@@ -10,7 +10,7 @@
 
 namespace hmrm {
 
-constexpr int kTopLevel = kMipLevels; // whole-map level (thr_max, no load)
+constexpr int kTopLevel = kMipLevels; // whole-map level: the one element of the pyramid's top plane
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
 __device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)(unsigned long long)__double_as_longlong(v); }

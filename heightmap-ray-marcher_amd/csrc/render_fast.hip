@@ -29,7 +29,7 @@
 // Pyramid layout (built by k_build_mip*): level l holds maxima of S x S-cell windows,
 // S = 4, 16, 64, 256, placed every S/2 cells (overlapping), so that a ray can always pick
 // a window in which it has at least S/2 cells of room ahead.  Values are floats
-// rounded UP (a larger bound is always safe).  Above them: the whole map (thr_max).
+// rounded UP (a larger bound is always safe).  Above them: the whole map, the one window of a top plane.
 #include "device_common.hpp"
 #include "leap_common.hpp"
 #include "leap_diag.hpp"
