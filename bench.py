@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--mode", choices=["frames", "strips"], default="frames")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="frames mode: consecutive frames go to this many HIP streams round-robin, so that the thin tail "
+                         "of one launch overlaps the start of the next (1 = one stream, launches back to back)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -175,13 +178,27 @@ def main():
     algo_bytes = 8 * frame_steps + 4 * frame_rays + 4 * frame_hits
 
     orbit = None
+    in_flight = 1
     if (world == 1 and not force_dist) or args.mode == "frames":
-        out = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+        # Frames are independent (hmap.cpp:978-983, and the recording loop :1131-1144 renders one after the other):
+        # consecutive frames go round-robin to `in_flight` streams, each with its own device frame.
+        in_flight = max(1, min(args.frames_in_flight, 4))
+        extra_streams = [torch.cuda.Stream() for _ in range(in_flight - 1)]  # (kept alive until main returns)
+        lanes = [(h, torch.empty((H, W, 4), dtype=torch.uint8, device="cuda"))
+                 for h in [stream] + [x.cuda_stream for x in extra_streams]]
+        out = lanes[0][1]
+        issued = {"n": 0}
+
+        def next_lane():
+            lane = lanes[issued["n"] % in_flight]
+            issued["n"] += 1
+            return lane
         if world == 1 and not force_dist:
             def step():
-                scene.render_rows_device(cam, out.data_ptr(), W * 4, 0, H, stream=stream)
+                st_, o_ = next_lane()
+                scene.render_rows_device(cam, o_.data_ptr(), W * 4, 0, H, stream=st_)
             my_steps_timed = frame_steps * args.steps
-            parallelism = "1 GPU"
+            parallelism = "1 GPU" + (f", {in_flight} frames in flight on {in_flight} HIP streams" if in_flight > 1 else "")
         else:
             # BASELINE config C5's sharding: frame k of the 64-frame orbit on GPU k mod world
             mine = strips.orbit_frames_of_rank(rank, world, args.warmup + args.steps, ORBIT_FRAMES)
@@ -191,16 +208,19 @@ def main():
             # host set-up (libm calls, spherical tables) of up to 32 cameras per stream, so that the timed
             # laps around the orbit measure the GPU path like the static pose at N = 1 does
             for c in cams.values():
-                scene.render_rows_device(c, out.data_ptr(), W * 4, 0, H, stream=stream)
-            orbit = {"it": iter(mine), "last": None}
+                for st_, o_ in lanes:
+                    scene.render_rows_device(c, o_.data_ptr(), W * 4, 0, H, stream=st_)
+            orbit = {"it": iter(mine), "last": [None] * in_flight}
 
             def step():
                 k = next(orbit["it"])
-                orbit["last"] = k
-                scene.render_rows_device(cams[k], out.data_ptr(), W * 4, 0, H, stream=stream)
+                orbit["last"][issued["n"] % in_flight] = k
+                st_, o_ = next_lane()
+                scene.render_rows_device(cams[k], o_.data_ptr(), W * 4, 0, H, stream=st_)
             my_steps_timed = sum(steps_of[k] for k in mine[args.warmup:])
             parallelism = (f"{ORBIT_FRAMES}-frame orbit, frame k on GPU k mod {world} "
-                           f"({args.steps} frames per GPU), no collective")
+                           f"({args.steps} frames per GPU), no collective"
+                           + (f"; {in_flight} frames in flight per GPU" if in_flight > 1 else ""))
         rays_per_step = frame_rays * world
         scaling = "weak"
     else:
@@ -250,13 +270,27 @@ def main():
     # correctness of what was just timed: every rank's last frame equals what the instrumented
     # kernel (another instantiation, host read-back path) renders for the same camera
     if orbit is not None:
-        want = scene.render_stats(cams[orbit["last"]])[0]
-        if not np.array_equal(out.cpu().numpy(), want):
-            raise SystemExit(f"bench.py: rank {rank} rendered a different orbit frame {orbit['last']} than hmrm_render_stats")
-    elif rank == 0:
-        got = (result["frame"] if ((world > 1 or force_dist) and args.mode == "strips") else out).cpu().numpy()
-        if not np.array_equal(got, fb_ref):
+        for (st_, o_), k in zip(lanes, orbit["last"]):
+            if k is not None and not np.array_equal(o_.cpu().numpy(), scene.render_stats(cams[k])[0]):
+                raise SystemExit(f"bench.py: rank {rank} rendered a different orbit frame {k} than hmrm_render_stats")
+    elif (world > 1 or force_dist) and args.mode == "strips":
+        if rank == 0 and not np.array_equal(result["frame"].cpu().numpy(), fb_ref):
             raise SystemExit("bench.py: timed path produced a different frame than hmrm_render_stats")
+    else:
+        for st_, o_ in lanes[:min(in_flight, args.warmup + args.steps)]:
+            if not np.array_equal(o_.cpu().numpy(), fb_ref):
+                raise SystemExit("bench.py: timed path produced a different frame than hmrm_render_stats")
+    # the same K steps launched back to back on ONE stream (untimed region; reported beside `value`)
+    single = None
+    if in_flight > 1 and orbit is None and world == 1 and not force_dist:
+        for _ in range(50 + args.warmup):  # (the frame checks above left the GPU idle: back to steady clocks first)
+            scene.render_rows_device(cam, out.data_ptr(), W * 4, 0, H, stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            scene.render_rows_device(cam, out.data_ptr(), W * 4, 0, H, stream=stream)
+        torch.cuda.synchronize()
+        single = (time.perf_counter() - t1) / args.steps
 
 
     if rank == 0:
@@ -297,6 +331,8 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "equivalent_steps": True,
+            "frames_in_flight": in_flight,
+            "one_stream": ({"ms_per_step": single * 1e3, "value": frame_steps / single} if single else None),
             "executed_per_frame": {"height_samples": int(st.groups) * 4 if st.groups else None,
                                    "pyramid_lookups": int(st.leap_attempts),
                                    "steps_covered_by_exact_leaps": int(st.leaped_steps)},
