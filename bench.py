@@ -311,6 +311,8 @@ def main():
         roofline = {
             "bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s", "frac": frac,
             "frac_if_every_valu_held_the_pipe_4_cycles": (busy_upper / kernel_s / 1e9 / peak) if busy_upper else None,
+            # (the line above is rocprofv3's derived metric VALUBusy = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), here at
+            # the 2.4 GHz peak clock; `frac` prices the instruction classes at their measured pipe cost instead)
             "traffic": traffic,
             "hbm": {"achieved": (traffic / kernel_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None},
