@@ -233,12 +233,12 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							room_b = room; // steps left inside the three binades
 							room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
 							room = __builtin_fmin(room, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
-							room = __builtin_fmin(room, (double)budget);
 							room_z = sz < 0.0 ? (m - z) * az.rdel : 0x1p40;
 							z_bound = room_z < room;
 							room = __builtin_fmin(room, room_z);
-							room = __builtin_fmin(__builtin_fmax(room, 0.0), 0x1p30);
-							n = (int)(room * 0.998) - 1;
+							// (the saturating cast takes care of huge and negative estimates; the step budget caps the
+							// integer: a jump never takes more steps than the cap has left)
+							n = min(cvt_i32_sat(room * 0.998), budget) - 1;
 							can = inb0 && exact && above && n >= kMinLeap;
 							// landing point and its exact verification
 							const double nn = (double)n;
@@ -247,8 +247,9 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
 							if (GWM == 2 && nearn) { qxn = xn / f.grid_width; qyn = -yn / f.grid_width; }
 							const int gxn = cvt_i32_sat(qxn), gyn = GWM == 0 ? cvt_i32_sat_neg(yn) : cvt_i32_sat(qyn);
-							const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim;
-							ok = can && inbn && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
+							const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim; // (diagnostics only)
+							// (inside the window implies inside the grid: the spans were cut at the map's edge)
+							ok = can && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
 							     (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
 							     axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
 							diag.on_landing_refused(f, can && !ok, inbn,
