@@ -183,9 +183,10 @@ def main():
         # Frames are independent (hmap.cpp:978-983, and the recording loop :1131-1144 renders one after the other):
         # consecutive frames go round-robin to `in_flight` streams, each with its own device frame.
         in_flight = max(1, min(args.frames_in_flight, 4))
-        extra_streams = [torch.cuda.Stream() for _ in range(in_flight - 1)]  # (kept alive until main returns)
+        # (with frames in flight every lane gets a stream of its own: the default stream would be one of them otherwise)
+        own_streams = [torch.cuda.Stream() for _ in range(in_flight)] if in_flight > 1 else []  # (alive until main returns)
         lanes = [(h, torch.empty((H, W, 4), dtype=torch.uint8, device="cuda"))
-                 for h in [stream] + [x.cuda_stream for x in extra_streams]]
+                 for h in ([x.cuda_stream for x in own_streams] or [stream])]
         out = lanes[0][1]
         issued = {"n": 0}
 

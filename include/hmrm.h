@@ -18,7 +18,9 @@
  * Threading (the reference's loop is an OpenMP region over read-only globals, hmap.cpp:978): a scene may
  * be used from several host threads.  Everything a launch mutates -- spherical tables, counters, the
  * cache of per-frame records -- is kept per HIP stream, so hmrm_render_rows_device calls on different
- * streams run concurrently on the device; the host-side set-up of a call is serialised per scene.  The
+ * streams run concurrently on the device (a scene keeps that state for the 32 most recently used streams;
+ * driving it from more makes every launch wait for the stream whose state it takes over); the host-side
+ * set-up of a call is serialised per scene.  The
  * entry points that return pixels in host memory (hmrm_render, _stats, _cycle, _multi) use the scene's own
  * stream and scratch frame: one such call at a time per scene.  hmrm_render_begin may be called while
  * other tickets are in flight.  hmrm_scene_update and hmrm_scene_destroy require that no launch of that

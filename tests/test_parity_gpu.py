@@ -1073,3 +1073,29 @@ def test_map_with_a_side_of_2_pow_24_cells(gpu, oracle):
         scene.render(_bilinear(cam))
     assert e.value.code == gpu.HMRM_E_ARG and "2^24" in str(e.value)
     scene.close()
+
+
+def test_many_streams_round_robin_and_recycled_stream_state(gpu, oracle):
+    """Frames in flight (bench.py's default): consecutive frames go round-robin to a dozen HIP streams, and then to
+    forty -- more than the scene keeps launch state for, so states are recycled between launches.  Every frame of
+    every stream equals the oracle's."""
+    import torch
+    rgb, cmap = scenes.small_maps(96, 96, 67)
+    params = gpu.SceneParams.make(0.0, 10.0, grid_width=1.0)
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+    W, H = 160, 90
+    cams = [gpu.Camera.make(width=W, height=H, projection=2, hfov=gpu.degrees_to_rads(150), hang=gpu.degrees_to_rads(h),
+                            vang=gpu.degrees_to_rads(112), pos=(-20.0, 20.0, 30.0), step_dist=0.25, bg=(1, 2, 3))
+            for h in (-45, -30, -60)]
+    want = [oracle.render(oracle.make_cfg(c, params, 96, 96), heights, cmap)[0] for c in cams]
+    for nstreams in (12, 40):
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+        bufs = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2 * nstreams)]
+        torch.cuda.synchronize()
+        for k in range(2 * nstreams):
+            scene.render_rows_device(cams[k % 3], bufs[k].data_ptr(), W * 4, 0, H, stream=streams[k % nstreams].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(2 * nstreams):
+            assert np.array_equal(bufs[k].cpu().numpy(), want[k % 3]), (nstreams, k)
+    scene.close()

@@ -14,7 +14,7 @@ W, H = cam.width, cam.height
 N = 240
 for orbit in (False, True):
     cams = [wl.camera(k, 24) for k in range(24)] if orbit else [cam]
-    for S in (1, 2, 3, 4):
+    for S in [int(x) for x in os.environ.get("STREAMS", "1,2,3,4").split(",")]:
         streams = [torch.cuda.Stream() for _ in range(S)]
         outs = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(S)]
         def run(n):
