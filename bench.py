@@ -206,7 +206,7 @@ def main():
             cams = {k: wl.camera(k, ORBIT_FRAMES) for k in sorted(set(mine))}
             steps_of = {k: int(scene.render_stats(c)[1].steps) for k, c in cams.items()}  # untimed, instrumented
             # every camera of this rank once on the timed stream, untimed: the library keeps the per-frame
-            # host set-up (libm calls, spherical tables) of up to 32 cameras per stream, so that the timed
+            # host set-up (libm calls, spherical tables) of up to 64 cameras per stream, so that the timed
             # laps around the orbit measure the GPU path like the static pose at N = 1 does
             for c in cams.values():
                 for st_, o_ in lanes:

@@ -78,7 +78,7 @@ Knobs read_knobs() {
 } // namespace
 
 constexpr int kCostRows = 8;
-constexpr int kFrameSlots = 32;  // cached per-frame records (and spherical tables) per stream: a 64-frame orbit over 2+ GPUs fits
+constexpr int kFrameSlots = 64;  // cached per-frame records (and spherical tables) per stream: a 64-frame orbit fits
 constexpr int kMaxStreamCtx = 32; // streams a scene keeps launch state for (more: the least recently used one is recycled, with a stream sync)
 
 // One cached per-frame record: the result of the host set-up (camera.cpp) for one camera, and for
