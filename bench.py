@@ -301,19 +301,27 @@ def main():
         pmc, prov = _pmc_from_profiles(wl.name, hmrm.kernel_src_sha())
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         valu = (pmc or {}).get("valu") or {}
-        busy = valu.get("busy_cycles_weighted")
+        # VALU pipe-busy cycles per launch, three ways (tools/pmc_summary.py): `isa` = SQ_INSTS_VALU x the calibrated
+        # pipe cost of the march loop's own instruction mix (tools/isa_cost.py on the compiler's assembly,
+        # profiles/r02_valu_calibration.txt) -- the best estimate, and `frac`; `weighted` prices only the classes the
+        # counters separate and everything else as a 2.3-cycle instruction -- a lower bound; `upper` =
+        # SQ_ACTIVE_INST_VALU x 4, i.e. rocprofv3's derived metric VALUBusy, which charges every instruction 4 cycles.
+        busy_lower = valu.get("busy_cycles_weighted")
         busy_upper = valu.get("busy_cycles_upper")
+        busy = valu.get("busy_cycles_isa") or busy_lower
         peak = SIMDS * PEAK_CLOCK_GHZ  # G SIMD-cycles/s
         achieved = busy / kernel_s / 1e9 if busy else None
         frac = achieved / peak if achieved else None
         if frac is not None and frac > 1.0:  # a fraction above 1 would mean the pricing is wrong: do not print it
-            prov["status"] += "; weighted VALU figure exceeded the peak and was dropped"
+            prov["status"] += "; the priced VALU figure exceeded the peak and was dropped"
             achieved = frac = None
         roofline = {
             "bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s", "frac": frac,
-            "frac_if_every_valu_held_the_pipe_4_cycles": (busy_upper / kernel_s / 1e9 / peak) if busy_upper else None,
-            # (the line above is rocprofv3's derived metric VALUBusy = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x cycles), here at
-            # the 2.4 GHz peak clock; `frac` prices the instruction classes at their measured pipe cost instead)
+            "frac_basis": ("SQ_INSTS_VALU x %.2f cycles (the loop's instruction mix at calibrated pipe costs)"
+                           % valu["cycles_per_inst_isa"]) if valu.get("busy_cycles_isa") else
+                          ("counter-separable classes priced, the rest at 2.3 cycles (lower bound)" if busy_lower else None),
+            "frac_lower_bound": (busy_lower / kernel_s / 1e9 / peak) if busy_lower else None,
+            "frac_if_every_valu_held_the_pipe_4_cycles": (busy_upper / kernel_s / 1e9 / peak) if busy_upper else None,  # = VALUBusy
             "traffic": traffic,
             "hbm": {"achieved": (traffic / kernel_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None},

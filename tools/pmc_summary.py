@@ -115,6 +115,21 @@ if "SQ_INSTS_VALU" in frame:
     if have_classes:
         valu["busy_cycles_weighted"] = (CYC_F64 * f64 + CYC_TRANS64 * trans + CYC_CVT * cvt +
                                         CYC_OTHER * max(n - f64 - trans - cvt, 0.0))
+    # Best estimate: every instruction priced at its calibrated pipe cost, with the kernel's own instruction mix --
+    # the march loop of the instantiation that ran, read from the compiler's assembly (tools/isa_cost.py)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import isa_cost
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "heightmap-ray-marcher_amd", "csrc"), "asm"], check=True,
+                       capture_output=True)
+        fast = [k for k in per_kernel if k.startswith("k_render_fast<")] or [k for k in durations if k.startswith("k_render_fast<")]
+        lc = isa_cost.loop_cost(isa_cost.mangled(fast[0][fast[0].index("<") + 1:fast[0].rindex(">")])) if fast else None
+        if lc:
+            valu["loop_valu_insts_static"], valu["loop_cycles_static"] = lc[0], lc[1]
+            valu["cycles_per_inst_isa"] = lc[1] / lc[0]
+            valu["busy_cycles_isa"] = n * lc[1] / lc[0]
+    except (OSError, subprocess.CalledProcessError, ValueError, IndexError) as e:
+        lines.append(f"(no instruction-priced estimate: {e})")
     entry["valu"] = valu
     lines.append(f"VALU per frame: {n:.0f} wave-instructions; fp64 add/mul/fma {f64:.0f}, fp64 rcp/sqrt {trans:.0f}, conversions {cvt:.0f}")
 if "SQ_THREAD_CYCLES_VALU" in frame and "SQ_ACTIVE_INST_VALU" in frame:
@@ -124,6 +139,9 @@ if frame_ns and "valu" in entry:
     simd_cycles = SIMDS * frame_ns * 1e-9 * PEAK_CLOCK_HZ
     lines.append(f"SIMD-cycles available per frame at 2.4 GHz over {frame_ns / 1e3:.1f} us: {simd_cycles:.3e}; "
                  f"VALU busy: upper {entry['valu']['busy_cycles_upper'] / simd_cycles:.3f}"
+                 + (f", instruction-priced {entry['valu']['busy_cycles_isa'] / simd_cycles:.3f} "
+                    f"({entry['valu']['cycles_per_inst_isa']:.2f} cycles per instruction of the loop's mix)"
+                    if entry['valu'].get('busy_cycles_isa') else "")
                  + (f", weighted {entry['valu']['busy_cycles_weighted'] / simd_cycles:.3f}"
                     if entry['valu'].get('busy_cycles_weighted') else ""))
 

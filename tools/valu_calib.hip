@@ -94,6 +94,19 @@ __global__ __launch_bounds__(256) void k_calib(double *out, int iters, double se
 				if (MODE == 28) asm volatile("s_and_b64 vcc, s[20:21], exec\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(c[i]) : "v"(inv) : "vcc", "scc");
 				if (MODE == 29) asm volatile("s_and_b64 s[22:23], s[20:21], exec\n\tv_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(c[i]) : "v"(inv) : "s22", "s23", "scc");
 				if (MODE == 30) asm volatile("v_cmp_lt_f64 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_add_u32 %1, %1, %4\n\tv_cndmask_b32 %1, %1, %4, vcc" : "+v"(c[i]), "+v"(c[(i + 3) % kAcc]) : "v"(a[i]), "v"(s), "v"(inv) : "vcc");
+				// 32-bit integer forms the render loop uses besides plain VOP2 add / logic (tools/isa_cost.py's classes)
+				if (MODE == 31) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(c[i]) : "v"(c[(i + 1) % kAcc]));
+				if (MODE == 32) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(c[i]) : "v"(c[(i + 1) % kAcc]));
+				if (MODE == 33) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(c[i]) : "v"(c[(i + 1) % kAcc]));
+				if (MODE == 34) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(c[i]) : "v"(c[(i + 1) % kAcc]));
+				if (MODE == 35) asm volatile("v_max_i32 %0, %0, %1" : "+v"(c[i]) : "v"(c[(i + 1) % kAcc]));
+				if (MODE == 36) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(c[i]));
+				if (MODE == 37) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a[i]) : "v"(b[i]));
+				if (MODE == 38) asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(a[i]));
+				if (MODE == 39) asm volatile("v_cmp_eq_u32 vcc, %0, %1" : : "v"(c[i]), "v"(c[(i + 1) % kAcc]) : "vcc");
+				if (MODE == 40) asm volatile("v_mov_b64 %0, %1" : "=v"(a[i]) : "v"(s));
+				if (MODE == 41) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(c[i]) : "v"(c[(i + 1) % kAcc]));
+				if (MODE == 42) asm volatile("v_cvt_i32_f64_e64 %0, -%1" : "=v"(c[i]) : "v"(a[i]));
 				if (MODE == 24) asm volatile("v_cmp_lt_f64 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc" : "+v"(c[i]), "+v"(c[(i + 3) % kAcc]) : "v"(a[i]), "v"(s), "v"(inv) : "vcc");
 			}
 		}
@@ -163,6 +176,18 @@ int main(int argc, char **argv) {
 	if (run<28>("s_and vcc + cndmask e32", d_out, blocks, iters, 1)) return 1;
 	if (run<29>("s_and sgpr + cndmask_e64", d_out, blocks, iters, 1)) return 1;
 	if (run<30>("cmp_f64->vcc, cnd, add, cnd", d_out, blocks, iters / 2, 4)) return 1;
+	if (run<31>("v_add3_u32", d_out, blocks, iters, 1)) return 1;
+	if (run<32>("v_lshl_add_u32", d_out, blocks, iters, 1)) return 1;
+	if (run<33>("v_mad_u32_u24", d_out, blocks, iters, 1)) return 1;
+	if (run<34>("v_and_or_b32", d_out, blocks, iters, 1)) return 1;
+	if (run<35>("v_max_i32", d_out, blocks, iters, 1)) return 1;
+	if (run<36>("v_ashrrev_i32", d_out, blocks, iters, 1)) return 1;
+	if (run<37>("v_cvt_f64_f32", d_out, blocks, iters, 1)) return 1;
+	if (run<38>("v_lshl_add_u64", d_out, blocks, iters, 1)) return 1;
+	if (run<39>("v_cmp_eq_u32 -> vcc", d_out, blocks, iters, 1)) return 1;
+	if (run<40>("v_mov_b64", d_out, blocks, iters, 1)) return 1;
+	if (run<41>("v_xor_b32", d_out, blocks, iters, 1)) return 1;
+	if (run<42>("v_cvt_i32_f64 (-src)", d_out, blocks, iters, 1)) return 1;
 	CK(hipDeviceSynchronize());
 	return 0;
 }
