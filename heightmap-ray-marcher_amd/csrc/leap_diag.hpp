@@ -139,6 +139,7 @@ struct LoopDiag<true> {
 		if (f.diag_mode == 2) return (uint32_t)(__builtin_amdgcn_s_memtime() - t_start); // wave cycles
 		if (f.diag_mode == 3) return (uint32_t)t_start;
 		if (f.diag_mode == 17 || f.diag_mode == 18) return (uint32_t)x0;
+		if (f.diag_mode == 19) return ((attempts > 0xffffu ? 0xffffu : attempts) << 16) | (leaps > 0xffffu ? 0xffffu : leaps);
 		return steps > 0xffffffffull ? 0xffffffffu : (uint32_t)steps;
 	}
 	__device__ __forceinline__ void publish(const StatsOut &st, const DevFrame &f) {

@@ -160,8 +160,8 @@ lib, EXPORTED_SYMBOLS = _load()
 
 # Device + launch sources: a PMC summary (profiles/traffic.json) is only valid for the kernel it was
 # collected on, so it carries this hash and bench.py refuses one that does not match the tree.
-KERNEL_SOURCES = ("render_fast.hip", "render.hip", "device_common.hpp", "frame.hpp", "render.hpp", "api.cpp",
-                  "camera.cpp", "Makefile")
+KERNEL_SOURCES = ("render_fast.hip", "leap_common.hpp", "leap_diag.hpp", "render.hip", "device_common.hpp", "frame.hpp",
+                  "render.hpp", "api.cpp", "camera.cpp", "Makefile")
 
 
 def kernel_src_sha() -> str:
