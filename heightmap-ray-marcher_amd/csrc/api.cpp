@@ -738,8 +738,8 @@ int hmrm_render_rows_device(const hmrm_scene *scene, const hmrm_camera *cam, voi
 	int rc = check_camera(cam);
 	if (rc) return rc;
 	if (!s || !d_rgba) return fail(HMRM_E_ARG, "NULL argument");
-	if (stride_bytes < (size_t)cam->width * 4 || (stride_bytes & 3))
-		return fail(HMRM_E_ARG, "stride_bytes must be >= width*4 and a multiple of 4");
+	if (stride_bytes < (size_t)cam->width * 4 || (stride_bytes & 3) || stride_bytes / 4 > 0x7fffffffu)
+		return fail(HMRM_E_ARG, "stride_bytes must be >= width*4, a multiple of 4 and below 2^33");
 	hmrm::RowMap rows{};
 	if (band_rows > 0) {
 		if (band_count <= 0 || band_index < 0 || band_index >= band_count)

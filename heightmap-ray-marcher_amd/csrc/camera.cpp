@@ -15,6 +15,7 @@
 #include "frame.hpp"
 
 #include <cmath>
+#include <cstring>
 
 namespace hmrm {
 namespace {
@@ -127,6 +128,18 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min
 	f->c1[0] = f->c0[0] + map_w * grid_width;
 	f->c1[1] = f->c0[1] - map_h * grid_width;
 	f->c1[2] = max_height;
+
+	for (int i = 0; i < 3; ++i) {
+		auto high = [](double v) {
+			uint64_t b;
+			memcpy(&b, &v, sizeof b);
+			return (uint32_t)(b >> 32);
+		};
+		const uint32_t h0 = high(f->c0[i] - cam.pos[i]), h1 = high(f->c1[i] - cam.pos[i]);
+		const bool moderate = (((h0 >> 20) & 0x7ffu) - 523u) < 1000u && (((h1 >> 20) & 0x7ffu) - 523u) < 1000u;
+		f->box_side_known[i] = (moderate && ((h0 ^ h1) >> 31) == 0u) ? 1 : 0;
+		f->box_side[i] = f->box_side_known[i] ? h0 : 0u;
+	}
 
 	f->grid_width = grid_width;
 	f->nudge = grid_width * 0.01; // hmap.cpp:998

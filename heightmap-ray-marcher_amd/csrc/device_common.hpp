@@ -108,10 +108,22 @@ __device__ __forceinline__ bool slab_surely_misses(const DevRay &r, const DevFra
 // With all three numbers finite, non-zero and of moderate exponent (2^-500 .. 2^499) both
 // exact quotients are finite, non-zero and negative, so that axis' dim_hi < 0 and
 // distance() (AABB.cpp:49-77) ends in inf or in an entry distance <= hi < 0: a miss.
+// PROJ 1 / 2: the origin is the camera for every ray, so the two box-side tests are done once per frame on the
+// host (camera.cpp, DevFrame::box_side) and a ray only adds the sign and the exponent of its direction.
+template <int PROJ>
 __device__ __forceinline__ bool slab_points_away(const DevRay &r, const DevFrame &f) {
 	const double ro[3] = {r.px, r.py, r.pz};
 	const double rd[3] = {r.dx, r.dy, r.dz};
 	bool away = false;
+	if (PROJ != 3) {
+#pragma unroll
+		for (int i = 0; i < 3; ++i) {
+			if (!f.box_side_known[i]) continue; // (uniform)
+			const uint32_t hd = (uint32_t)((unsigned long long)__double_as_longlong(rd[i]) >> 32);
+			away = away | ((((hd >> 20) & 0x7ffu) - 523u) < 1000u & ((f.box_side[i] ^ hd) >> 31) != 0u);
+		}
+		return away;
+	}
 #pragma unroll
 	for (int i = 0; i < 3; ++i) {
 		const uint32_t h0 = (uint32_t)((unsigned long long)__double_as_longlong(f.c0[i] - ro[i]) >> 32);
@@ -128,11 +140,18 @@ __device__ __forceinline__ uint32_t pack_rgba(uint32_t r, uint32_t g, uint32_t b
 	return r | (g << 8) | (b << 16) | 0xff000000u; // bytes R,G,B,A=255 (hmap.cpp:150-153)
 }
 
-// Clamp<double>(v,0,255) then floor then (Uint8), hmap.cpp:1049-1051
-__device__ __forceinline__ uint32_t sky_channel(double v) {
+// Clamp<double>(v,0,255) then floor then (Uint8), hmap.cpp:1049-1051, as written there (the literal kernel's)
+__device__ __forceinline__ uint32_t sky_channel_literal(double v) {
 	if (v < 0.0) v = 0.0;
 	else if (v > 255.0) v = 255.0;
 	return (uint32_t)(int)__builtin_floor(v);
+}
+// The same for the values shade_miss produces: v is
+// a sum of non-negative terms (a weight times z or z*z with z > 0, plus a colour byte), never NaN and never
+// negative, possibly +inf.  So the lower clamp never acts, min(v, 255) is the upper one, and the truncating
+// cast equals the floor.
+__device__ __forceinline__ uint32_t sky_channel(double v) {
+	return (uint32_t)__builtin_fmin(v, 255.0);
 }
 
 struct StatsOut {

@@ -50,7 +50,15 @@ struct DevFrame {
 	const float *mipbuf_bil;     // the same pyramid over the 3x3-dilated table (bilinear quality mode)
 	int32_t mip_row;             // row pitch of every plane (windows per row of level 0)
 	int32_t mip_plane_shift;     // log2 of the plane pitch
-	int32_t pad_mip_[6];
+	// Perspective / spherical: every ray starts at cam, so on which side of the origin the box lies per axis
+	// is a property of the frame (device_common.hpp slab_points_away): box_side[i] = high word of
+	// c0[i] - cam[i] when c0[i] - cam[i] and c1[i] - cam[i] are finite, non-zero, of moderate exponent and
+	// of one sign (its sign bit is the side), else 0 with box_side_known[i] = 0.
+	// (Kept inside the struct's old size on purpose.  The struct is the kernel argument; a field appended at its
+	// end that the miss shade reads -- the background as doubles -- made EVERY wave wait for one more 64-byte
+	// line of it at start-up, the compiler hoists scalar loads to the entry: +3...5 % on the all-terrain frames.)
+	uint32_t box_side[3];
+	int32_t box_side_known[3];
 	int32_t diag_mode;           // tools only: what the instrumented kernel writes per pixel
 	int32_t sampling;            // 0 nearest cell (the reference), 1 bilinear quality mode, 2 nearest cell with float thresholds
 	int32_t min_level;           // finest pyramid level worth an attempt (api.cpp, from min_window)

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_render(const DevFrame f, cons
 				const double r_ = 220.0 * zz + (double)f.bg[0];
 				const double g_ = 240.0 * zz + (double)f.bg[1];
 				const double b_ = 255.0 * ray.dz + (double)f.bg[2];
-				rgba = pack_rgba(sky_channel(r_), sky_channel(g_), sky_channel(b_));
+				rgba = pack_rgba(sky_channel_literal(r_), sky_channel_literal(g_), sky_channel_literal(b_));
 			} else {
 				rgba = pack_rgba(f.bg[0], f.bg[1], f.bg[2]);
 			}

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 		const DevRay ray = make_ray<PROJ>(f, pid.px, pid.py);
 		// most rays of a frame never touch the box: prove the miss cheaply where possible
 		// (the instrumented variant always runs the exact test, it reports d)
-		const double d = (!STATS && (slab_points_away(ray, f) || slab_surely_misses(ray, f))) ? __builtin_huge_val()
+		const double d = (!STATS && (slab_points_away<PROJ>(ray, f) || slab_surely_misses(ray, f))) ? __builtin_huge_val()
 		                                                                                  : slab_distance(ray, f);
 		if (STATS && st.entry_d) st.entry_d[(int64_t)pid.py * f.screen_w + pid.px] = d;
 
@@ -418,7 +418,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 
 		if (real_hit) my_hit = 1;
 		else rgba = shade_miss(f, ray.dz);
-		out[(int64_t)pid.lrow * out_stride_px + pid.px] = rgba;
+		// (row and pitch are below 2^31, api.cpp: one 32 x 32 -> 64-bit multiply-add)
+		out[(uint64_t)(uint32_t)pid.lrow * (uint32_t)out_stride_px + (uint32_t)pid.px] = rgba;
 		if (STATS && st.steps_per_pixel)
 			st.steps_per_pixel[(int64_t)pid.py * f.screen_w + pid.px] = diag.pixel_value(f, my_steps);
 	}

@@ -175,6 +175,7 @@ int hmrm_render_cycle(const hmrm_scene *scene, const hmrm_camera *cam,
 /* Same pass restricted to rows [row_begin,row_end) of the frame, written to a
  * DEVICE buffer that holds only those rows (row row_begin at d_rgba), enqueued
  * on `hip_stream` (a hipStream_t, NULL = default stream) without a host sync.
+ * stride_bytes: a multiple of 4, at least width*4, below 2^33.
  * This is the multi-GPU row-strip entry point. `band_rows`>0 selects cyclic
  * banding: the strip holds bands band_index, band_index+band_count, ... of
  * band_rows rows each, packed back to back (row_begin/row_end then ignored). */
