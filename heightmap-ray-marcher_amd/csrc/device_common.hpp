@@ -103,6 +103,50 @@ __device__ __forceinline__ bool slab_surely_misses(const DevRay &r, const DevFra
 	return HI < 0.0 || (LO - HI) > mag * 0x1p-12;
 }
 
+// The same approximate slab parameters also settle most HITS with one division instead of six.  For finite
+// quotients distance() returns lo = max_i min(t0_i, t1_i) when lo <= hi = min_i max(t0_i, t1_i), else inf
+// (its early returns are that comparison on a prefix of the axes).  If the approximate values show, by more than
+// their error bars, (a) that the intervals overlap, (b) which axis holds the maximum of the lower ends and (c)
+// which of its two quotients is the lower end, then the exact result is that ONE quotient, correctly rounded:
+// rounding is monotonic, so the exact quotients are ordered like the approximate ones wherever those differ by
+// more than the margin.  (Margin 2^-30 of the largest |t'|; the reciprocal-multiply error is below 2^-48 of it.)
+// Returns 0: undecided, take slab_distance(); 1: surely a miss (only when `may_report_miss`; d is not set);
+// 2: *d is distance()'s value, bit for bit (it may be negative: the caller's d < 0 test applies as usual).
+__device__ __forceinline__ int slab_classify(const DevRay &r, const DevFrame &f, bool may_report_miss, double *d) {
+	const double ro[3] = {r.px, r.py, r.pz};
+	const double rd[3] = {r.dx, r.dy, r.dz};
+	const double inf = __builtin_huge_val();
+	double LO = -inf, LO2 = -inf, HI = inf, mag = 0.0;
+	double num = 0.0, den = 1.0, span = 0.0; // of the axis that holds LO: entry numerator, direction, |t0' - t1'|
+	bool fine = true;
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		fine = fine & (__builtin_fabs(rd[i]) > 0x1p-500) & (__builtin_fabs(rd[i]) < 0x1p500);
+		const double inv = __builtin_amdgcn_rcp(rd[i]);
+		const double n0 = f.c0[i] - ro[i], n1 = f.c1[i] - ro[i];
+		const double t0 = n0 * inv, t1 = n1 * inv;
+		fine = fine & (__builtin_fabs(t0) < 0x1p500) & (__builtin_fabs(t1) < 0x1p500);
+		const bool first = t0 < t1;
+		const double lo_i = first ? t0 : t1, hi_i = first ? t1 : t0;
+		const bool bigger = lo_i > LO;
+		LO2 = bigger ? LO : __builtin_fmax(LO2, lo_i);
+		num = bigger ? (first ? n0 : n1) : num;
+		den = bigger ? rd[i] : den;
+		span = bigger ? hi_i - lo_i : span;
+		LO = bigger ? lo_i : LO;
+		HI = __builtin_fmin(HI, hi_i);
+		mag = __builtin_fmax(mag, __builtin_fmax(__builtin_fabs(t0), __builtin_fabs(t1)));
+	}
+	if (!fine) return 0;
+	if (may_report_miss && (HI < 0.0 || (LO - HI) > mag * 0x1p-12)) return 1;
+	const double margin = mag * 0x1p-30;
+	if ((HI - LO) > margin && (LO - LO2) > margin && span > margin) {
+		*d = num / den;
+		return 2;
+	}
+	return 0;
+}
+
 // Cheaper still, from sign and exponent bits alone: on some axis the whole box lies on one
 // side of the origin (c0-o and c1-o have the same sign) and the ray points the other way.
 // With all three numbers finite, non-zero and of moderate exponent (2^-500 .. 2^499) both

@@ -128,10 +128,15 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 
 	if (pid.live) {
 		const DevRay ray = make_ray<PROJ>(f, pid.px, pid.py);
-		// most rays of a frame never touch the box: prove the miss cheaply where possible
-		// (the instrumented variant always runs the exact test, it reports d)
-		const double d = (!STATS && (slab_points_away<PROJ>(ray, f) || slab_surely_misses(ray, f))) ? __builtin_huge_val()
-		                                                                                  : slab_distance(ray, f);
+		// most rays of a frame never touch the box: prove the miss cheaply where possible (the instrumented
+		// variant reports d, so it takes no shortcut for misses); most of the others get their entry distance
+		// from one division instead of six (slab_classify: the instrumented variant uses that path too, so the
+		// parity tests compare its d with the oracle's bit for bit)
+		double d = __builtin_huge_val();
+		if (STATS || !slab_points_away<PROJ>(ray, f)) {
+			const int verdict = slab_classify(ray, f, !STATS, &d);
+			if (verdict == 0) d = slab_distance(ray, f);
+		}
 		if (STATS && st.entry_d) st.entry_d[(int64_t)pid.py * f.screen_w + pid.px] = d;
 
 		uint32_t rgba = 0;
