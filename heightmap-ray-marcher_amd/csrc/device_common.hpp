@@ -77,33 +77,15 @@ __device__ __forceinline__ double slab_distance(const DevRay &r, const DevFrame 
 	return (lo > hi) ? inf : lo;
 }
 
-// Cheap proof that slab_distance() would report a miss (inf, or an entry distance < 0:
-// AABB.cpp:33-40), from approximate reciprocals.  Each approximate slab parameter t'
-// has the sign of the exact quotient and a relative error far below 2^-16, so:
+// Cheap classification of a ray against the box from approximate reciprocals (one v_rcp_f64 and two multiplies per
+// axis).  Each approximate slab parameter t' has the sign of the exact quotient and a relative error far below
+// 2^-16, so a MISS is proven when
 //   (A) min_i hi'_i < 0          => the exact hi is negative => d <= hi < 0 or d = inf;
 //   (B) max_i lo'_i exceeds min_i hi'_i by more than the error bars => the exact intervals
 //       do not overlap => distance() returns inf (early or at its last line).
-// Either way the pixel is a miss; nothing else about d is used for a miss.  Returns false
-// ("don't know", take the exact path) whenever a direction component is zero or anything
-// is non-finite.
-__device__ __forceinline__ bool slab_surely_misses(const DevRay &r, const DevFrame &f) {
-	const double ro[3] = {r.px, r.py, r.pz};
-	const double rd[3] = {r.dx, r.dy, r.dz};
-	double LO = -__builtin_huge_val(), HI = __builtin_huge_val(), mag = 0.0;
-#pragma unroll
-	for (int i = 0; i < 3; ++i) {
-		if (!(__builtin_fabs(rd[i]) > 0x1p-500) || !(__builtin_fabs(rd[i]) < 0x1p500)) return false;
-		const double inv = __builtin_amdgcn_rcp(rd[i]);
-		const double t0 = (f.c0[i] - ro[i]) * inv, t1 = (f.c1[i] - ro[i]) * inv;
-		if (!(__builtin_fabs(t0) < 0x1p500) || !(__builtin_fabs(t1) < 0x1p500)) return false;
-		LO = __builtin_fmax(LO, __builtin_fmin(t0, t1));
-		HI = __builtin_fmin(HI, __builtin_fmax(t0, t1));
-		mag = __builtin_fmax(mag, __builtin_fmax(__builtin_fabs(t0), __builtin_fabs(t1)));
-	}
-	return HI < 0.0 || (LO - HI) > mag * 0x1p-12;
-}
-
-// The same approximate slab parameters also settle most HITS with one division instead of six.  For finite
+// Either way the pixel is a miss (AABB.cpp:33-40); nothing else about d is used for a miss.  "Don't know" (take the
+// exact path) whenever a direction component is zero or anything is non-finite.
+// The same approximate parameters also settle most HITS with one division instead of six.  For finite
 // quotients distance() returns lo = max_i min(t0_i, t1_i) when lo <= hi = min_i max(t0_i, t1_i), else inf
 // (its early returns are that comparison on a prefix of the axes).  If the approximate values show, by more than
 // their error bars, (a) that the intervals overlap, (b) which axis holds the maximum of the lower ends and (c)
