@@ -64,6 +64,11 @@ def bits(v):
 
 
 def run(cases, rng):
+    with np.errstate(all="ignore"):  # (non-finite intermediates are part of the cases)
+        return _run(cases, rng)
+
+
+def _run(cases, rng):
     decided = misses = 0
     for o, d, c0, c1 in cases:
         o, d, c0, c1 = (np.asarray(v, dtype=np.float64) for v in (o, d, c0, c1))
