@@ -18,6 +18,7 @@
 #include "../../include/hmrm.h"
 #include "config.hpp"
 #include "frame.hpp"
+#include "host_pool.hpp"
 #include "image_io.hpp"
 #include "render.hpp"
 
@@ -77,7 +78,7 @@ Knobs read_knobs() {
 
 } // namespace
 
-constexpr int kCostRows = 8;
+constexpr int kCostRows = 16; // one sample row per 16-row tile row (render_tile_shape)
 constexpr int kFrameSlots = 64;  // cached per-frame records (and spherical tables) per stream: a 64-frame orbit fits
 constexpr int kMaxStreamCtx = 32; // streams a scene keeps launch state for (more: the least recently used one is recycled, with a stream sync)
 
@@ -107,6 +108,8 @@ struct StreamCtx {
 	// [0] steps [1] hits [2] capped rays (cumulative, never reset) [4..7] traversal diagnostics
 	unsigned long long *d_counters = nullptr;
 	unsigned long long capped_seen = 0; // value of [2] the host has already reported
+	// recorded behind every launch: what a recycled context waits for (the caller's stream handle may be gone by then)
+	hipEvent_t last_launch = nullptr;
 };
 
 // One slot of the asynchronous read-back ring (hmrm_render_begin/_wait/_release): a device frame
@@ -175,11 +178,12 @@ void destroy_ctx(StreamCtx *c) {
 		if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
 	}
 	if (c->d_counters) (void)hipFree(c->d_counters);
+	if (c->last_launch) (void)hipEventDestroy(c->last_launch);
 	delete c;
 }
 
 // The launch state of `stream` (created on first use; the least recently used one is dropped, after
-// its stream has drained, when a scene is driven from more than kMaxStreamCtx streams).
+// its last launch has finished, when a scene is driven from more than kMaxStreamCtx streams).
 int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 	for (StreamCtx *c : s->ctxs)
 		if (c->stream == stream) {
@@ -191,7 +195,9 @@ int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 		size_t victim = 1; // (never the scene's own stream, entry 0)
 		for (size_t i = 2; i < s->ctxs.size(); ++i)
 			if (s->ctxs[i]->stamp < s->ctxs[victim]->stamp) victim = i;
-		(void)hipStreamSynchronize(s->ctxs[victim]->stream);
+		// its kernels may still read the tables / counters about to be freed.  The stream belongs to the caller and
+		// may have been destroyed since (no call may name it any more): wait on the context's own event instead
+		(void)hipEventSynchronize(s->ctxs[victim]->last_launch);
 		destroy_ctx(s->ctxs[victim]);
 		s->ctxs.erase(s->ctxs.begin() + (long)victim);
 	}
@@ -200,6 +206,7 @@ int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 	c->stream = stream;
 	c->stamp = ++s->clock;
 	hipError_t e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_launch, hipEventDisableTiming);
 	// (zeroed on the scene's stream and waited for: the caller's stream may be anything)
 	if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -317,7 +324,30 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 		}
 		hmrm::DevFrame &fr = slot->frame;
 		hmrm::build_frame(hc, s->map_w, s->map_h, s->params.min_height, s->params.max_height, s->params.grid_width,
-		                  &fr, cc, cs, rs, rc);
+		                  &fr, nullptr, nullptr, nullptr, nullptr);
+		if (cam->projection == HMRM_SPHERICAL) {
+			// A moving camera seldom changes everything: the row tables (sin / cos of va) depend on vang, hfov and
+			// the resolution only -- they survive any orbit or translation -- and the column tables on hang, hfov
+			// and the width.  A half some cached record of this stream already holds is copied from its staging
+			// memory; what is left is filled by the host pool (glibc sin / cos, ~15 ns per call: 12 000 calls for
+			// a fresh 4K camera would otherwise cost more host time than the kernel takes on the GPU).
+			const FrameSlot *row_donor = nullptr, *col_donor = nullptr;
+			for (const FrameSlot &o : c->slots) {
+				if (!o.valid || &o == slot || o.cam.projection != HMRM_SPHERICAL || !o.h_tables) continue;
+				if (o.cam.width != cam->width || o.cam.hfov != cam->hfov) continue;
+				if (!col_donor && o.cam.hang == cam->hang) col_donor = &o;
+				if (!row_donor && o.cam.height == cam->height && o.cam.vang == cam->vang) row_donor = &o;
+			}
+			if (col_donor) memcpy(cc, col_donor->h_tables, 2 * W * sizeof(double));
+			if (row_donor) memcpy(rs, row_donor->h_tables + 2 * (size_t)row_donor->cam.width, 2 * H * sizeof(double));
+			const int nc = col_donor ? 0 : cam->width, nr = row_donor ? 0 : cam->height;
+			if (nc + nr > 0)
+				hmrm::parallel_ranges(nc + nr, 1024, [&](int b, int e) {
+					// items [0, nc) are columns, [nc, nc + nr) rows
+					if (b < nc) hmrm::fill_col_tables(hc, b, std::min(e, nc), cc, cs);
+					if (e > nc) hmrm::fill_row_tables(hc, std::max(b, nc) - nc, e - nc, rs, rc);
+				});
+		}
 		slot->row_cost.assign(((size_t)cam->height + kCostRows - 1) / kCostRows, 0.0f);
 		hmrm::estimate_row_costs(fr, cc, cs, rs, rc, kCostRows, slot->row_cost.data());
 		if (cam->projection == HMRM_SPHERICAL) {
@@ -385,11 +415,13 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const Fra
 	if ((s->knobs.kernel == 2 || huge_side) && f.sampling == 0) { // (the literal loop only knows the reference's sampling)
 		HIP_TRY(hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters, d_steps,
 		                            d_entry, stats, c->stream));
-		return HMRM_OK;
+	} else {
+		const bool leap = s->knobs.kernel != 1;
+		HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
+		                                 c->d_counters, d_steps, d_entry, stats, leap, c->stream));
 	}
-	const bool leap = s->knobs.kernel != 1;
-	HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px, c->d_counters,
-	                                 d_steps, d_entry, stats, leap, c->stream));
+	// (only streams other than the scene's own can be recycled, ctx_for)
+	if (c->stream != s->stream) HIP_TRY(hipEventRecord(c->last_launch, c->stream));
 	return HMRM_OK;
 }
 
@@ -788,25 +820,38 @@ int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_ca
 	const int n = std::min<int>(n_scenes, (H + kBand - 1) / kBand);
 	for (int i = 0; i < n; ++i)
 		if (!scenes[i]) return fail(HMRM_E_ARG, "NULL scene");
-	for (int i = 0; i < n; ++i) {
+	// (an error part-way leaves copies of the scenes already launched in flight into the caller's frame: they are
+	// drained before the call returns, the caller may free `rgba` at once)
+	auto enqueue = [&](int i) -> int {
 		hmrm_scene *s = scenes[i];
 		HIP_TRY(hipSetDevice(s->device));
 		std::lock_guard<std::mutex> lk(s->mu);
 		const int32_t local = hmrm_band_local_rows(H, kBand, i, n);
-		if ((rc = ensure_frame(s, W * (size_t)local))) return rc;
+		int rc2;
+		if ((rc2 = ensure_frame(s, W * (size_t)local))) return rc2;
 		StreamCtx *c = nullptr;
-		if ((rc = ctx_for(s, s->stream, &c))) return rc;
+		if ((rc2 = ctx_for(s, s->stream, &c))) return rc2;
 		hmrm::DevFrame f;
 		FrameSlot *slot = nullptr;
-		if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
+		if ((rc2 = prepare_frame(s, c, cam, &f, &slot))) return rc2;
 		hmrm::RowMap rows{0, local, kBand, i, n, 0};
-		if ((rc = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;
+		if ((rc2 = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc2;
 		// band b of this scene's strip is frame rows [(i + b*n) * kBand, ...): contiguous in both
 		for (int b = 0; (i + b * n) * kBand < H; ++b) {
 			const int row0 = (i + b * n) * kBand, nrows = std::min(kBand, H - row0);
 			HIP_TRY(hipMemcpy2DAsync(rgba + (size_t)row0 * stride_bytes, stride_bytes,
 			                         s->d_frame + (size_t)b * kBand * W, W * 4, W * 4, (size_t)nrows,
 			                         hipMemcpyDeviceToHost, s->stream));
+		}
+		return HMRM_OK;
+	};
+	for (int i = 0; i < n; ++i) {
+		if ((rc = enqueue(i)) != HMRM_OK) {
+			const std::string keep = g_error;
+			for (int j = 0; j <= i; ++j)
+				if (hipSetDevice(scenes[j]->device) == hipSuccess) (void)hipStreamSynchronize(scenes[j]->stream);
+			g_error = keep;
+			return rc;
 		}
 	}
 	unsigned long long capped = 0;
@@ -863,11 +908,19 @@ int hmrm_render_begin(const hmrm_scene *scene, const hmrm_camera *cam, int32_t *
 		if ((int)s->ring.size() >= kMaxRing) return fail(HMRM_E_ARG, "hmrm_render_begin: every frame of the ring is in use (release one)");
 		RingFrame *r = new (std::nothrow) RingFrame();
 		if (!r) return fail(HMRM_E_ARG, "out of memory");
+		// (complete before it joins the ring: a half-made slot would be picked up as free by the next call)
+		hipError_t e = hipEventCreateWithFlags(&r->kernel_done, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&r->copy_done, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipHostMalloc((void **)&r->h_capped, sizeof(unsigned long long), hipHostMallocDefault);
+		if (e != hipSuccess) {
+			if (r->kernel_done) (void)hipEventDestroy(r->kernel_done);
+			if (r->copy_done) (void)hipEventDestroy(r->copy_done);
+			if (r->h_capped) (void)hipHostFree(r->h_capped);
+			delete r;
+			return fail(HMRM_E_DEVICE, std::string("hmrm_render_begin: ") + hipGetErrorString(e));
+		}
 		s->ring.push_back(r);
 		idx = (int)s->ring.size() - 1;
-		HIP_TRY(hipEventCreateWithFlags(&r->kernel_done, hipEventDisableTiming));
-		HIP_TRY(hipEventCreateWithFlags(&r->copy_done, hipEventDisableTiming));
-		HIP_TRY(hipHostMalloc((void **)&r->h_capped, sizeof(unsigned long long), hipHostMallocDefault));
 	}
 	RingFrame *r = s->ring[(size_t)idx];
 	if (W * H > r->px) {
@@ -1165,6 +1218,25 @@ int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam, int32_t px, 
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	for (int i = 0; i < 3; ++i) { pos[i] = host[i]; dir[i] = host[3 + i]; }
 	*entry_d = host[6];
+	return HMRM_OK;
+}
+
+// v_rcp_f64 accuracy on this device (render.hip k_rcp_error): the premise of slab_classify's margins.
+int hmrm_debug_rcp_error(int32_t mode, uint64_t count, uint64_t seed, int32_t exp_lo, int32_t exp_hi,
+                         double *max_rel_err, uint64_t *hist64) {
+	if (!max_rel_err) return fail(HMRM_E_ARG, "NULL argument");
+	if (mode < 0 || mode > 2 || count == 0 || count > ((uint64_t)1 << 40) || exp_lo > exp_hi || exp_lo < -1000 || exp_hi > 1000)
+		return fail(HMRM_E_ARG, "hmrm_debug_rcp_error: bad mode, count or exponent range");
+	unsigned long long *d = nullptr, host[65] = {};
+	HIP_TRY(hipMalloc((void **)&d, sizeof host));
+	hipError_t e = hipMemset(d, 0, sizeof host);
+	if (e == hipSuccess) e = hmrm::launch_rcp_error(mode, count, seed, exp_lo, exp_hi, d, nullptr);
+	if (e == hipSuccess) e = hipMemcpy(host, d, sizeof host, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(HMRM_E_DEVICE, std::string("rcp probe: ") + hipGetErrorString(e));
+	memcpy(max_rel_err, &host[0], sizeof(double));
+	if (hist64)
+		for (int i = 0; i < 64; ++i) hist64[i] = host[1 + i];
 	return HMRM_OK;
 }
 

@@ -51,6 +51,32 @@ inline void store(double dst[3], Vec3 v) {
 
 } // namespace
 
+// Spherical.cpp:18-25 is separable: ha (and so cos ha, sin ha) depends on the column only, va on the row only.
+// Columns [begin, end) of the W-entry tables; glibc's cos / sin, one call per value as in the reference.
+void fill_col_tables(const HostCamera &cam, int32_t begin, int32_t end, double *col_cos_ha, double *col_sin_ha) {
+	const double hfov = cam.hfov;
+	const double ul_hang = cam.hang + (hfov / 2.0);            // Spherical.cpp:12
+	for (int32_t px = begin; px < end; ++px) {
+		const double w = (double)px / (cam.width - 1);          // hmap.cpp:986
+		const double ha = ul_hang - w * hfov;                   // Spherical.cpp:18
+		col_cos_ha[px] = std::cos(ha);
+		col_sin_ha[px] = std::sin(ha);
+	}
+}
+
+// Rows [begin, end) of the H-entry tables.
+void fill_row_tables(const HostCamera &cam, int32_t begin, int32_t end, double *row_sin_va, double *row_cos_va) {
+	const double aspect = (double)cam.width / cam.height;      // hmap.cpp:955-956
+	const double vfov = cam.hfov / aspect;                     // Spherical.cpp:11
+	const double ul_vang = cam.vang - (vfov / 2.0);            // Spherical.cpp:13
+	for (int32_t py = begin; py < end; ++py) {
+		const double h = (double)py / (cam.height - 1);         // hmap.cpp:987
+		const double va = ul_vang + h * vfov;                   // Spherical.cpp:19
+		row_sin_va[py] = std::sin(va);
+		row_cos_va[py] = std::cos(va);
+	}
+}
+
 void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min_height,
                  double max_height, double grid_width, DevFrame *f, double *col_cos_ha,
                  double *col_sin_ha, double *row_sin_va, double *row_cos_va) {
@@ -91,23 +117,10 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min
 		store(f->plane_right, ur - ul);
 		store(f->plane_down, ll - ul);
 	} else if (cam.projection == 2) {
-		// src/Spherical.cpp:11-14, then the separable halves of :18-25
-		const double hfov = cam.hfov;
-		const double vfov = hfov / aspect;
-		const double ul_hang = hang + (hfov / 2.0);
-		const double ul_vang = vang - (vfov / 2.0);
-		for (int32_t px = 0; px < cam.width; ++px) {
-			const double w = (double)px / (cam.width - 1); // hmap.cpp:986
-			const double ha = ul_hang - w * hfov;
-			col_cos_ha[px] = std::cos(ha);
-			col_sin_ha[px] = std::sin(ha);
-		}
-		for (int32_t py = 0; py < cam.height; ++py) {
-			const double h = (double)py / (cam.height - 1); // hmap.cpp:987
-			const double va = ul_vang + h * vfov;
-			row_sin_va[py] = std::sin(va);
-			row_cos_va[py] = std::cos(va);
-		}
+		// src/Spherical.cpp:11-14, then the separable halves of :18-25 (callers that fill the tables
+		// in pieces -- api.cpp, on several host threads -- pass null here and call the two fills themselves)
+		if (col_cos_ha && col_sin_ha) fill_col_tables(cam, 0, cam.width, col_cos_ha, col_sin_ha);
+		if (row_sin_va && row_cos_va) fill_row_tables(cam, 0, cam.height, row_sin_va, row_cos_va);
 	} else {
 		// src/Orthographic.cpp:5-16
 		const Vec3 lk = through_float(look);
@@ -164,48 +177,6 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min
 	f->min_window = cells_per_step > 0.35 ? 16 : 4;
 	f->finest_pause = cells_per_step > 0.35 ? 3 : 0;
 	f->min_level = 0; // (api.cpp turns min_window into a level of the pyramid it built)
-}
-
-void estimate_row_costs(const DevFrame &f, const double *col_cos_ha, const double *col_sin_ha,
-                        const double *row_sin_va, const double *row_cos_va, int rows_per_sample, float *out) {
-	const int W = f.screen_w, H = f.screen_h;
-	const int n = (H + rows_per_sample - 1) / rows_per_sample;
-	const int kCols = 9;
-	for (int k = 0; k < n; ++k) {
-		int py = k * rows_per_sample + rows_per_sample / 2;
-		if (py > H - 1) py = H - 1;
-		double best = 0.0;
-		for (int c = 0; c < kCols; ++c) {
-			const int px = (int)((int64_t)(W - 1) * c / (kCols - 1));
-			double o[3], d[3];
-			if (f.projection == 2) {
-				o[0] = f.cam[0]; o[1] = f.cam[1]; o[2] = f.cam[2];
-				d[0] = row_sin_va[py] * col_cos_ha[px];
-				d[1] = row_sin_va[py] * col_sin_ha[px];
-				d[2] = row_cos_va[py];
-			} else {
-				const double w = W > 1 ? (double)px / (W - 1) : 0.0, h = H > 1 ? (double)py / (H - 1) : 0.0;
-				double p[3];
-				for (int i = 0; i < 3; ++i) p[i] = f.upper_left[i] + w * f.plane_right[i] + h * f.plane_down[i];
-				if (f.projection == 1) {
-					for (int i = 0; i < 3; ++i) { o[i] = f.cam[i]; d[i] = p[i] - f.cam[i]; }
-					const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-					for (int i = 0; i < 3; ++i) d[i] /= len;
-				} else {
-					for (int i = 0; i < 3; ++i) { o[i] = p[i]; d[i] = f.look[i]; }
-				}
-			}
-			double lo = 0.0, hi = HUGE_VAL; // the part of the ray in front of its origin
-			for (int i = 0; i < 3; ++i) {
-				const double t0 = (f.c0[i] - o[i]) / d[i], t1 = (f.c1[i] - o[i]) / d[i];
-				lo = std::fmax(lo, std::fmin(t0, t1)); // (fmin/fmax drop a NaN operand)
-				hi = std::fmin(hi, std::fmax(t0, t1));
-			}
-			const double steps = (hi - lo) / std::fabs(f.step_dist);
-			if (steps > best && std::isfinite(steps)) best = steps;
-		}
-		out[k] = (float)best;
-	}
 }
 
 } // namespace hmrm

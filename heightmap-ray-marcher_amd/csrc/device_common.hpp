@@ -77,28 +77,41 @@ __device__ __forceinline__ double slab_distance(const DevRay &r, const DevFrame 
 	return (lo > hi) ? inf : lo;
 }
 
+// Relative error of the hardware reciprocal.  MEASURED on gfx950 (tools/rcp_accuracy.py over 1.6e11 inputs: the
+// leading 32 mantissa bits exhaustively in six binades, hashed mantissas / signs / exponents 2^-1000..2^1000, and the
+// product n * rcp(d) against n / d; profiles/r03_rcp_accuracy.txt): |rcp(x) * x - 1| <= 2^-24.36 everywhere, the same
+// in every binade -- a 24-bit result, as AMD's ISA guides say ("(2**29) ULP").  tests/test_parity_gpu.py
+// re-measures a slice in every GPU run and fails if the device at hand exceeds kRcpRelErr.
+constexpr double kRcpRelErr = 0x1p-24;
+// ... and the margin every ordering decision below keeps between two approximate slab parameters, as a fraction of
+// the largest of them: 16 x kRcpRelErr.  (Needed: 2 x (kRcpRelErr + 2^-53), one error bar per operand.)
+constexpr double kSlabMargin = 16.0 * kRcpRelErr; // 2^-20
+
 // Cheap classification of a ray against the box from approximate reciprocals (one v_rcp_f64 and two multiplies per
-// axis).  Each approximate slab parameter t' has the sign of the exact quotient and a relative error far below
-// 2^-16, so a MISS is proven when
+// axis).  With every direction component and every product of moderate magnitude (2^-500..2^500: no overflow, no
+// underflow, no zero) an approximate slab parameter is t' = t (1 + e), |e| <= kRcpRelErr + 2^-53, of the exact real
+// quotient t: same sign, and two of them that differ by more than kSlabMargin * max|t'| are ordered like the exact
+// quotients -- hence, rounding being monotonic, their correctly rounded values (the reference's) are ordered the same
+// way or equal.  So a MISS is proven when
 //   (A) min_i hi'_i < 0          => the exact hi is negative => d <= hi < 0 or d = inf;
-//   (B) max_i lo'_i exceeds min_i hi'_i by more than the error bars => the exact intervals
-//       do not overlap => distance() returns inf (early or at its last line).
+//   (B) max_i lo'_i exceeds min_i hi'_i by more than the error bars (2^-12 of the largest: far more) => the exact
+//       intervals do not overlap => distance() returns inf (early or at its last line).
 // Either way the pixel is a miss (AABB.cpp:33-40); nothing else about d is used for a miss.  "Don't know" (take the
-// exact path) whenever a direction component is zero or anything is non-finite.
+// exact path) whenever a direction component or a parameter is zero, tiny, huge or not finite.
 // The same approximate parameters also settle most HITS with one division instead of six.  For finite
 // quotients distance() returns lo = max_i min(t0_i, t1_i) when lo <= hi = min_i max(t0_i, t1_i), else inf
 // (its early returns are that comparison on a prefix of the axes).  If the approximate values show, by more than
-// their error bars, (a) that the intervals overlap, (b) which axis holds the maximum of the lower ends and (c)
-// which of its two quotients is the lower end, then the exact result is that ONE quotient, correctly rounded:
-// rounding is monotonic, so the exact quotients are ordered like the approximate ones wherever those differ by
-// more than the margin.  (Margin 2^-30 of the largest |t'|; the reciprocal-multiply error is below 2^-48 of it.)
+// the margin, (a) that the intervals overlap, (b) which axis holds the maximum of the lower ends and (c) which of its
+// two quotients is the lower end, then the exact result is that ONE quotient, correctly rounded (where two rounded
+// lower ends coincide the value is the same whichever axis supplied it).  Rays through an edge or a corner of the
+// box (lower ends within 2^-20 of each other) stay undecided and take the reference's six divisions.
 // Returns 0: undecided, take slab_distance(); 1: surely a miss (only when `may_report_miss`; d is not set);
 // 2: *d is distance()'s value, bit for bit (it may be negative: the caller's d < 0 test applies as usual).
 __device__ __forceinline__ int slab_classify(const DevRay &r, const DevFrame &f, bool may_report_miss, double *d) {
 	const double ro[3] = {r.px, r.py, r.pz};
 	const double rd[3] = {r.dx, r.dy, r.dz};
 	const double inf = __builtin_huge_val();
-	double LO = -inf, LO2 = -inf, HI = inf, mag = 0.0;
+	double LO = -inf, LO2 = -inf, HI = inf, mag = 0.0, least = inf;
 	double num = 0.0, den = 1.0, span = 0.0; // of the axis that holds LO: entry numerator, direction, |t0' - t1'|
 	bool fine = true;
 #pragma unroll
@@ -107,7 +120,6 @@ __device__ __forceinline__ int slab_classify(const DevRay &r, const DevFrame &f,
 		const double inv = __builtin_amdgcn_rcp(rd[i]);
 		const double n0 = f.c0[i] - ro[i], n1 = f.c1[i] - ro[i];
 		const double t0 = n0 * inv, t1 = n1 * inv;
-		fine = fine & (__builtin_fabs(t0) < 0x1p500) & (__builtin_fabs(t1) < 0x1p500);
 		const bool first = t0 < t1;
 		const double lo_i = first ? t0 : t1, hi_i = first ? t1 : t0;
 		const bool bigger = lo_i > LO;
@@ -117,11 +129,15 @@ __device__ __forceinline__ int slab_classify(const DevRay &r, const DevFrame &f,
 		span = bigger ? hi_i - lo_i : span;
 		LO = bigger ? lo_i : LO;
 		HI = __builtin_fmin(HI, hi_i);
-		mag = __builtin_fmax(mag, __builtin_fmax(__builtin_fabs(t0), __builtin_fabs(t1)));
+		const double a0 = __builtin_fabs(t0), a1 = __builtin_fabs(t1);
+		mag = __builtin_fmax(mag, __builtin_fmax(a0, a1));
+		least = __builtin_fmin(least, __builtin_fmin(a0, a1)); // (NaN operands drop out here and are caught by mag / fine below)
+		fine = fine & !__builtin_isunordered(t0, t1);
 	}
-	if (!fine) return 0;
+	// every parameter finite and of moderate magnitude: the relative-error model above holds for each of them
+	if (!(fine & (mag < 0x1p500) & (least > 0x1p-500))) return 0;
 	if (may_report_miss && (HI < 0.0 || (LO - HI) > mag * 0x1p-12)) return 1;
-	const double margin = mag * 0x1p-30;
+	const double margin = mag * kSlabMargin;
 	if ((HI - LO) > margin && (LO - LO2) > margin && span > margin) {
 		*d = num / den;
 		return 2;

@@ -96,7 +96,7 @@ struct RowMap {
 
 // Host: fill everything except the table pointers / thr_max / step_cap.
 // Also fills the spherical tables (host arrays of screen_w / screen_h doubles) when
-// projection == 2.  Returns false on invalid arguments.
+// projection == 2 and the pointers are not null.
 struct HostCamera {
 	int32_t width, height, projection;
 	uint8_t bg_r, bg_g, bg_b, sampling;
@@ -108,6 +108,11 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h,
                  DevFrame *out,
                  double *col_cos_ha, double *col_sin_ha,   // width entries each (spherical) or null
                  double *row_sin_va, double *row_cos_va);  // height entries each (spherical) or null
+
+// The separable halves of Spherical::GetRay (src/Spherical.cpp:18-25), entries [begin, end): cos / sin of ha per
+// column (depend on hang, hfov, width), sin / cos of va per row (depend on vang, hfov, width, height).
+void fill_col_tables(const HostCamera &cam, int32_t begin, int32_t end, double *col_cos_ha, double *col_sin_ha);
+void fill_row_tables(const HostCamera &cam, int32_t begin, int32_t end, double *row_sin_va, double *row_cos_va);
 
 // Scheduling aid, approximate arithmetic: for every block of `rows_per_sample` screen rows the
 // longest in-box ray length (in steps) over a few sample columns of the block's middle row.

@@ -141,6 +141,12 @@ int hmrm_record_orbit_multi(hmrm_scene *const *scenes, int32_t n_scenes, const h
 			const int rc = hmrm_render_wait(scenes[i], fr.second, &pixels, nullptr);
 			if (rc != HMRM_OK && rc != HMRM_E_NOTERM) {
 				note_error(rc);
+				// the ticket left the in-flight list: give its ring slot back here, nobody else will
+				hmrm_render_release(scenes[i], fr.second);
+				{
+					std::lock_guard<std::mutex> lk(mu);
+					++free_slots[(size_t)i];
+				}
 				return false;
 			}
 			{

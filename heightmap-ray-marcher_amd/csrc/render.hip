@@ -179,6 +179,71 @@ __global__ void k_probe(const DevFrame f, int px, int py, double *__restrict__ o
 	out[6] = slab_distance(r, f);
 }
 
+// Accuracy probe for v_rcp_f64 (test hook; device_common.hpp slab_classify rests on the bound it reports).
+// For every sample x: r = rcp(x) and e = |fma(r, x, -1)|, which is |r - 1/x| / |1/x| up to a factor 1 + 2^-53
+// (r*x - 1 is formed exactly inside the fma and rounded once).  mode 0 walks the leading 32 mantissa bits
+// exhaustively (sample i has them = i; the 20 trailing bits are 0, all ones, or hashed, by `seed & 3`; exponent
+// exp_lo, positive); mode 1 hashes mantissa, sign and an exponent in [exp_lo, exp_hi]; mode 2 measures what the
+// shortcut really forms, t' = n * rcp(d) against the correctly rounded n / d (|t' - q| / |q|: the difference of two
+// neighbours is exact), with hashed n of exponent in [exp_lo, exp_hi] and direction-like d (exponent -40..0).
+// out[0] = max e as fp64 bits (positive doubles order like integers), hist[k] = samples with e in [2^-k, 2^-(k-1)).
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+	z += 0x9e3779b97f4a7c15ull;
+	z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+	z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+	return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_rcp_error(int mode, uint64_t count, uint64_t seed, int exp_lo, int exp_hi,
+                                                   unsigned long long *__restrict__ out_max,
+                                                   unsigned long long *__restrict__ hist) {
+	__shared__ unsigned int lh[64];
+	if (threadIdx.x < 64) lh[threadIdx.x] = 0u;
+	__syncthreads();
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	double worst = 0.0;
+	const unsigned span = (unsigned)(exp_hi - exp_lo + 1);
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+		const uint64_t h = mix64(i ^ (seed * 0x9e3779b97f4a7c15ull));
+		double e;
+		if (mode == 2) {
+			const uint64_t h2 = mix64(h);
+			const uint64_t nb = (h & 0x800fffffffffffffull) | ((uint64_t)(1023 + exp_lo + (int)((h >> 52) % span)) << 52);
+			const uint64_t db = (h2 & 0x800fffffffffffffull) | ((uint64_t)(1023 - (int)((h2 >> 52) % 41u)) << 52);
+			const double n = __longlong_as_double((long long)nb), d = __longlong_as_double((long long)db);
+			const double t = n * __builtin_amdgcn_rcp(d), q = n / d;
+			e = __builtin_fabs(t - q) / __builtin_fabs(q);
+		} else {
+			uint64_t b;
+			if (mode == 0) {
+				const uint64_t low = (seed & 3) == 0 ? 0ull : ((seed & 3) == 1 ? 0xfffffull : (h & 0xfffffull));
+				b = ((uint64_t)(1023 + exp_lo) << 52) | ((i & 0xffffffffull) << 20) | low;
+			} else {
+				b = (h & 0x800fffffffffffffull) | ((uint64_t)(1023 + exp_lo + (int)((h >> 52) % span)) << 52);
+			}
+			const double x = __longlong_as_double((long long)b);
+			const double r = __builtin_amdgcn_rcp(x);
+			e = __builtin_fabs(__builtin_fma(r, x, -1.0));
+		}
+		worst = __builtin_fmax(worst, e);
+		// bin = -exponent of e, clamped to 0..63 (e == 0 -> 63)
+		int k = 1023 - (int)((((unsigned long long)__double_as_longlong(e)) >> 52) & 0x7ffu);
+		k = e == 0.0 ? 63 : (k < 0 ? 0 : (k > 63 ? 63 : k));
+		atomicAdd(&lh[k], 1u);
+	}
+	for (int off = 32; off > 0; off >>= 1) worst = __builtin_fmax(worst, __shfl_xor(worst, off));
+	if ((threadIdx.x & 63) == 0) atomicMax(out_max, (unsigned long long)__double_as_longlong(worst));
+	__syncthreads();
+	if (threadIdx.x < 64 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+hipError_t launch_rcp_error(int mode, uint64_t count, uint64_t seed, int exp_lo, int exp_hi,
+                            unsigned long long *d_out65, hipStream_t stream) {
+	// (a block's LDS histogram counts in 32 bits: at most 2^32 / 4096 blocks... keep every block below 2^31 samples)
+	hipLaunchKernelGGL(k_rcp_error, dim3(256 * 16), dim3(256), 0, stream, mode, count, seed, exp_lo, exp_hi, d_out65,
+	                   d_out65 + 1);
+	return hipGetLastError();
+}
+
 // ------------------------------------------------------------- launchers ----
 hipError_t launch_probe(const DevFrame &f, int px, int py, double *d_out7, hipStream_t stream) {
 	switch (f.projection) {

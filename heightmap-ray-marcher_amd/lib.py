@@ -109,6 +109,7 @@ def _load():
         "hmrm_render_stats": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(Stats), vp, vp]),
         "hmrm_debug_ray": (C.c_int, [vp, C.POINTER(Camera), i32, i32, dp, dp, dp]),
         "hmrm_debug_frame": (C.c_int, [C.POINTER(Camera), C.POINTER(SceneParams), i32, i32, vp, vp]),
+        "hmrm_debug_rcp_error": (C.c_int, [i32, C.c_uint64, C.c_uint64, i32, i32, dp, C.POINTER(C.c_uint64)]),
         "hmrm_last_kernel_ms": (C.c_double, []),
         "hmrm_bench_kernel_ms": (C.c_double, [vp, C.POINTER(Camera), i32]),
         "hmrm_orbit_camera": (None, [C.POINTER(Camera), C.c_double, C.c_double, C.c_double, C.c_double, i32, i32,
@@ -342,6 +343,14 @@ def debug_frame(cam: Camera, params: SceneParams, map_w: int, map_h: int):
         rec.update(col_cos_ha=tables[0:W], col_sin_ha=tables[W:2 * W],
                    row_sin_va=tables[2 * W:2 * W + H], row_cos_va=tables[2 * W + H:])
     return rec
+
+
+def rcp_error(mode: int, count: int, seed: int = 0, exp_lo: int = 0, exp_hi: int = 0):
+    """Largest relative error of v_rcp_f64 over a sample (hmrm_debug_rcp_error) -> (max_rel_err, hist[64])."""
+    m = C.c_double()
+    hist = (C.c_uint64 * 64)()
+    _check(lib.hmrm_debug_rcp_error(mode, count, seed, exp_lo, exp_hi, C.byref(m), hist))
+    return m.value, np.array(hist[:], dtype=np.uint64)
 
 
 def orbit_camera(base: Camera, centre_x: float, centre_y: float, radius: float, hang0: float,

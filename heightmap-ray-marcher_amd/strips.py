@@ -7,6 +7,10 @@ and terrain rows thousands, so contiguous H/world strips would be badly
 unbalanced.  The only collective is the final gather of the RGBA8 strips to rank
 0 (torch.distributed: RCCL over xGMI with backend "nccl", gloo in CPU tests).
 
+A second variant needs no collective at all: every rank copies its strip to ITS OWN pinned host
+memory over its own PCIe link (`render_strip_to_host`; what hmrm_render_multi does inside one
+process) -- the gather funnels (world-1)/world of the frame through rank 0's links, this does not.
+
 The renderer is passed in as a callable so that the same plan/gather/reassemble
 code runs with the HIP path on GPUs and with any row renderer in CPU tests.
 """
@@ -91,3 +95,26 @@ def render_frame_distributed(plan: BandPlan, rank: int, render_rows, dist, strip
     if rank != 0:
         return None
     return reassemble_torch(plan, block)
+
+
+def render_strip_to_host(plan: BandPlan, rank: int, render_rows, strip, host_strip, sync=None):
+    """The no-collective variant: this rank's bands into `strip` (device), then one copy of the strip
+    into `host_strip` (pinned host tensor of the same shape) over this rank's own link.  `sync()`
+    (e.g. torch.cuda.synchronize) is called afterwards when given.  The frame then exists as
+    `world` host strips; `strip_rows_match` / `reassemble_numpy` say where each row lives."""
+    render_rows(strip, plan.band_rows, rank, plan.world)
+    host_strip.copy_(strip, non_blocking=True)
+    if sync is not None:
+        sync()
+    return host_strip
+
+
+def strip_rows_match(plan: BandPlan, rank: int, host_strip, frame) -> bool:
+    """Does `host_strip` (this rank's strip) hold exactly its rows of `frame` ((height, width, 4))?"""
+    hs, fr = np.asarray(host_strip), np.asarray(frame)
+    for k, b in enumerate(plan.bands_of(rank)):
+        g0 = b * plan.band_rows
+        g1 = min(g0 + plan.band_rows, plan.height)
+        if not np.array_equal(hs[k * plan.band_rows:k * plan.band_rows + (g1 - g0)], fr[g0:g1]):
+            return False
+    return True

@@ -217,6 +217,17 @@ int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam,
 int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params,
                      int32_t map_w, int32_t map_h, double *out25, double *tables);
 
+/* Accuracy of the hardware reciprocal v_rcp_f64 on the current device (test hook; no reference counterpart:
+ * the reference divides, AABB.cpp:62-63, and the kernel's one-division shortcut through distance() must prove
+ * from approximate quotients which exact quotient is the result).  mode 0: the leading 32 mantissa bits
+ * exhaustively for exponent exp_lo (count = 2^32 covers them; trailing 20 bits 0 / all ones / hashed by
+ * seed & 3); mode 1: hashed mantissa, sign and exponent in [exp_lo, exp_hi]; mode 2: n * rcp(d) against the
+ * correctly rounded n / d for box-like n (exponent in [exp_lo, exp_hi]) and direction-like d (2^-40..1).
+ * *max_rel_err = largest relative error seen; hist64 (may be NULL) = 64 counters, [k] = samples with an
+ * error in [2^-k, 2^-(k-1)), [63] also holds the exact ones. */
+int hmrm_debug_rcp_error(int32_t mode, uint64_t count, uint64_t seed, int32_t exp_lo, int32_t exp_hi,
+                         double *max_rel_err, uint64_t *hist64);
+
 /* The environment knobs (HMRM_KERNEL, HMRM_STEP_CAP, ...) are read once, when a
  * scene is created; this re-reads them for a live scene (tests and tools switch kernel variants). */
 int hmrm_debug_reload_env(hmrm_scene *scene);

@@ -819,20 +819,64 @@ def test_c4_eight_rank_band_emulation_full_size(gpu, oracle):
     scene.close()
 
 
-@pytest.mark.parametrize("script,args", [("deep_fuzz.py", ["20260000", "1000000", "45"]),
-                                         ("deep_fuzz_big.py", ["20260000", "1000000", "45", "4096"])])
+@pytest.mark.parametrize("script,args", [("deep_fuzz.py", ["20260000", "1000000", "150"]),
+                                         ("deep_fuzz_big.py", ["20260000", "1000000", "150", "4096"]),
+                                         ("deep_fuzz_edges.py", ["20260000", "1000000", "100"])])
 def test_deep_fuzz_slice(gpu, script, args):
-    """A seeded 45-second slice of each long fuzzer (tests/deep_fuzz*.py: random maps from 1x1 up and
-    random cameras over the 4096^2 map, all projections and sampling modes, GPU vs oracle on frames,
-    per-ray step counts, distance() bits and cap counts) inside the suite the driver runs."""
+    """A seeded time-boxed slice of each long fuzzer (tests/deep_fuzz*.py: random maps from 1x1 up, random cameras
+    over the 4096^2 map, and cameras whose rays graze the box's edges and corners; all projections and sampling
+    modes, GPU vs oracle on frames, per-ray step counts, distance() bits and cap counts) inside the suite the
+    driver runs."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, script)] + args, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(here, script)] + args, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0 and "mismatches 0" in r.stdout, tail
     import re
     m = re.search(r"^scenes (\d+), mismatches 0|: cameras (\d+), mismatches 0", r.stdout, flags=re.M)
-    assert m and int(m.group(1) or m.group(2)) >= 50, tail
+    assert m and int(m.group(1) or m.group(2)) >= 150, tail
+    print(tail.strip().splitlines()[-1])  # (visible with -rP / in the junit output: how far the slice got)
+
+
+def test_rcp_f64_accuracy_bound(gpu):
+    """v_rcp_f64 on THIS device, measured: slab_classify's margins (device_common.hpp kRcpRelErr = 2^-24,
+    kSlabMargin = 16x that) hold only while the hardware reciprocal stays within that relative error.  The leading
+    32 mantissa bits exhaustively, hashed inputs over the whole exponent range, and the product the shortcut forms
+    (n * rcp(d) against n / d); the full sweep is tools/rcp_accuracy.py -> profiles/r03_rcp_accuracy.txt."""
+    bound = 2.0 ** -24
+    worst, n = 0.0, 0
+    lines = []
+    for args in ((0, 1 << 32, 2, 0, 0), (0, 1 << 32, 1, 0, 0), (1, 1 << 31, 11, -40, 0), (1, 1 << 31, 12, -1, 14),
+                 (1, 1 << 31, 13, -1000, 1000), (2, 1 << 31, 14, -10, 14), (2, 1 << 31, 15, -60, 60)):
+        m, hist = gpu.rcp_error(*args)
+        assert int(hist.sum()) == args[1]
+        lines.append(f"mode {args[0]} n {args[1]} seed {args[2]} exponents [{args[3]}, {args[4]}]: max rel err {m:.6e} = 2^{np.log2(m):.3f}")
+        worst, n = max(worst, m), n + args[1]
+    lines.append(f"total {n} inputs, worst {worst:.6e} = 2^{np.log2(worst):.3f}; bound used by the kernel 2^-24")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "rcp_accuracy_in_test.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    assert n >= (1 << 32) and 0.0 < worst <= bound, lines
+
+
+def test_rays_grazing_box_edges_and_corners(gpu, oracle):
+    """Adversarial for the one-division shortcut through distance() (AABB.cpp:49-77): frames whose neighbouring
+    rays pass an edge or a corner of the box at relative offsets 2^-14 .. 2^-52, on both sides, all three
+    projections (tests/deep_fuzz_edges.py; tests/test_slab_classify_model.py shows that 60 % of these rays fall
+    inside the shortcut's margin).  distance() bits, frames and per-ray step counts against the oracle."""
+    import deep_fuzz_edges as edges
+    cache = {}
+    strad = {1: 0, 2: 0, 3: 0}
+    fine = 0
+    for seed in range(900):
+        ok, s, cam, lg = edges.run_case(cache, oracle, scenes, seed)
+        assert ok, (seed, cam.projection, lg)
+        strad[cam.projection] += int(s)
+        fine += int(s and lg < -24)
+    for sc, *_ in cache.values():
+        sc.close()
+    # the frames do straddle silhouette edges, in every projection, also below the reciprocal's resolution
+    assert min(strad.values()) >= 60 and fine >= 100, (strad, fine)
 
 
 def test_progressive_cycle_refresh(gpu, oracle):

@@ -63,11 +63,22 @@ def _worker(rank, world, port, height, band_rows, result_path):
     block = torch.zeros((world, plan.strip_rows, plan.width, 4), dtype=torch.uint8) if rank == 0 else None
     frame = strips.render_frame_distributed(plan, rank, render_rows, dist, strip, block)
     dist.barrier()
+    # the no-collective variant: every rank keeps its strip in its own host memory; each checks its own rows and
+    # the verdicts are combined (bench.py's c4_strips.own_links leg does the same with its instrumented frame)
+    host_strip = torch.full((plan.strip_rows, plan.width, 4), 7, dtype=torch.uint8)
+    strips.render_strip_to_host(plan, rank, render_rows, strip, host_strip)
+    mine_ok = torch.tensor([int(strips.strip_rows_match(plan, rank, host_strip.numpy(), full))])
+    dist.all_reduce(mine_ok, op=dist.ReduceOp.MIN)
+    # (and a strip with one wrong pixel is noticed)
+    if plan.rows_of(rank):
+        wrong = host_strip.clone()
+        wrong[0, 0, 0] ^= 1
+        assert not strips.strip_rows_match(plan, rank, wrong.numpy(), full)
     if rank == 0:
         ok = bool(np.array_equal(frame.numpy(), full))
         also = bool(np.array_equal(strips.reassemble_numpy(plan, [block[i].numpy() for i in range(world)]), full))
         with open(result_path, "w") as f:
-            f.write(f"{int(ok)} {int(also)}")
+            f.write(f"{int(ok)} {int(also and int(mine_ok.item()) == 1)}")
     else:
         assert frame is None
     dist.destroy_process_group()
