@@ -93,9 +93,8 @@ struct FrameSlot {
 	uint64_t thr_max_bits = 0;
 	hmrm::DevFrame frame{};
 	std::vector<float> row_cost; // per kCostRows screen rows: longest in-box ray, in steps (launch order hint)
-	double *d_tables = nullptr;  // spherical sin/cos tables
-	double *h_tables = nullptr;  // pinned staging
-	size_t tables_n = 0;
+	double *d_tables = nullptr;  // spherical sin/cos tables: this slot's piece of the context's arenas
+	double *h_tables = nullptr;  // pinned staging, likewise
 	hipEvent_t uploaded = nullptr; // after the H2D copy out of h_tables: the host may rewrite them then
 };
 
@@ -105,6 +104,11 @@ struct StreamCtx {
 	hipStream_t stream = nullptr;
 	uint64_t stamp = 0;
 	FrameSlot slots[kFrameSlots];
+	// table storage of all slots: one device and one pinned allocation per context (a slot's first use would
+	// otherwise cost a hipMalloc + hipHostMalloc, ~0.1 ms each, in the middle of a sequence of frames)
+	double *d_arena = nullptr, *h_arena = nullptr;
+	double *h_arena_dev = nullptr; // the pinned arena as the device sees it (the upload kernel reads it)
+	size_t arena_n = 0; // doubles per slot
 	// [0] steps [1] hits [2] capped rays (cumulative, never reset) [4..7] traversal diagnostics
 	unsigned long long *d_counters = nullptr;
 	unsigned long long capped_seen = 0; // value of [2] the host has already reported
@@ -172,11 +176,10 @@ namespace {
 
 void destroy_ctx(StreamCtx *c) {
 	if (!c) return;
-	for (FrameSlot &sl : c->slots) {
-		if (sl.d_tables) (void)hipFree(sl.d_tables);
-		if (sl.h_tables) (void)hipHostFree(sl.h_tables);
+	for (FrameSlot &sl : c->slots)
 		if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
-	}
+	if (c->d_arena) (void)hipFree(c->d_arena);
+	if (c->h_arena) (void)hipHostFree(c->h_arena);
 	if (c->d_counters) (void)hipFree(c->d_counters);
 	if (c->last_launch) (void)hipEventDestroy(c->last_launch);
 	delete c;
@@ -303,18 +306,27 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 		const size_t W = (size_t)cam->width, H = (size_t)cam->height;
 		if (cam->projection == HMRM_SPHERICAL) {
 			const size_t n = 2 * W + 2 * H;
-			if (n > slot->tables_n) {
-				// (a kernel of this stream may still read the old tables)
+			if (n > c->arena_n) {
+				// (kernels of this stream may still read the old tables; every cached spherical record of the context
+				// loses its tables with the old arena)
 				HIP_TRY(hipStreamSynchronize(c->stream));
-				if (slot->d_tables) (void)hipFree(slot->d_tables);
-				if (slot->h_tables) (void)hipHostFree(slot->h_tables);
-				slot->d_tables = nullptr;
-				slot->h_tables = nullptr;
-				slot->tables_n = 0;
-				HIP_TRY(hipMalloc((void **)&slot->d_tables, n * sizeof(double)));
-				HIP_TRY(hipHostMalloc((void **)&slot->h_tables, n * sizeof(double), hipHostMallocDefault));
-				slot->tables_n = n;
+				if (c->d_arena) (void)hipFree(c->d_arena);
+				if (c->h_arena) (void)hipHostFree(c->h_arena);
+				c->d_arena = c->h_arena = nullptr;
+				c->arena_n = 0;
+				for (FrameSlot &sl : c->slots) {
+					if (sl.cam.projection == HMRM_SPHERICAL) sl.valid = false;
+					sl.d_tables = sl.h_tables = nullptr;
+				}
+				const size_t per = (n + 31) & ~(size_t)31; // (slots start on 256-byte boundaries)
+				HIP_TRY(hipMalloc((void **)&c->d_arena, per * kFrameSlots * sizeof(double)));
+				HIP_TRY(hipHostMalloc((void **)&c->h_arena, per * kFrameSlots * sizeof(double), hipHostMallocMapped));
+				HIP_TRY(hipHostGetDevicePointer((void **)&c->h_arena_dev, c->h_arena, 0));
+				c->arena_n = per;
 			}
+			const size_t idx = (size_t)(slot - c->slots);
+			slot->d_tables = c->d_arena + idx * c->arena_n;
+			slot->h_tables = c->h_arena + idx * c->arena_n;
 			if (!slot->uploaded) HIP_TRY(hipEventCreateWithFlags(&slot->uploaded, hipEventDisableTiming));
 			else HIP_TRY(hipEventSynchronize(slot->uploaded)); // the previous upload out of h_tables is done
 			cc = slot->h_tables;
@@ -351,10 +363,9 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 		slot->row_cost.assign(((size_t)cam->height + kCostRows - 1) / kCostRows, 0.0f);
 		hmrm::estimate_row_costs(fr, cc, cs, rs, rc, kCostRows, slot->row_cost.data());
 		if (cam->projection == HMRM_SPHERICAL) {
-			// stream order puts the copy behind every earlier kernel of this stream that read the
-			// slot's device tables and in front of the kernel about to be launched
-			HIP_TRY(hipMemcpyAsync(slot->d_tables, slot->h_tables, (2 * W + 2 * H) * sizeof(double),
-			                       hipMemcpyHostToDevice, c->stream));
+			// stream order puts the upload (a small kernel reading the pinned staging memory) behind every earlier
+			// kernel of this stream that read the slot's device tables and in front of the one about to be launched
+			HIP_TRY(hmrm::launch_upload_tables(c->h_arena_dev + (slot->h_tables - c->h_arena), slot->d_tables, 2 * W + 2 * H, c->stream));
 			HIP_TRY(hipEventRecord(slot->uploaded, c->stream));
 			fr.col_cos_ha = slot->d_tables;
 			fr.col_sin_ha = slot->d_tables + W;
@@ -1254,9 +1265,17 @@ int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params, in
 	hc.ortho_width = cam->ortho_width; hc.step_dist = cam->step_dist;
 	const size_t W = (size_t)cam->width, H = (size_t)cam->height;
 	hmrm::DevFrame f;
-	hmrm::build_frame(hc, map_w, map_h, params->min_height, params->max_height, params->grid_width, &f,
-	                  tables, tables ? tables + W : nullptr, tables ? tables + 2 * W : nullptr,
-	                  tables ? tables + 2 * W + H : nullptr);
+	hmrm::build_frame(hc, map_w, map_h, params->min_height, params->max_height, params->grid_width, &f, nullptr, nullptr,
+	                  nullptr, nullptr);
+	if (cam->projection == HMRM_SPHERICAL) {
+		// the tables exactly as a launch fills them: in pieces, on the host pool (prepare_frame)
+		double *cc = tables, *cs = tables + W, *rs = tables + 2 * W, *rc2 = tables + 2 * W + H;
+		const int nc = cam->width, nr = cam->height;
+		hmrm::parallel_ranges(nc + nr, 1024, [&](int b, int e) {
+			if (b < nc) hmrm::fill_col_tables(hc, b, std::min(e, nc), cc, cs);
+			if (e > nc) hmrm::fill_row_tables(hc, std::max(b, nc) - nc, e - nc, rs, rc2);
+		});
+	}
 	double *o = out25;
 	for (int i = 0; i < 3; ++i) *o++ = f.cam[i];
 	for (int i = 0; i < 3; ++i) *o++ = f.upper_left[i];

@@ -49,6 +49,9 @@ void render_tile_shape(int *tile_w, int *tile_h);
 // GetRay + distance() of pixel (px,py): d_out7 = pos[3], dir[3], d.
 hipError_t launch_probe(const DevFrame &f, int px, int py, double *d_out7, hipStream_t stream);
 
+// n doubles from pinned (device-mapped) host memory into device memory, as a kernel on `stream` (render.hip).
+hipError_t launch_upload_tables(const double *h_pinned, double *d_dst, size_t n, hipStream_t stream);
+
 // v_rcp_f64 accuracy probe (render.hip k_rcp_error): d_out65[0] = max relative error as fp64 bits, [1..64] = histogram
 // by binary order of magnitude; the caller zeroes d_out65.
 hipError_t launch_rcp_error(int mode, uint64_t count, uint64_t seed, int exp_lo, int exp_hi,

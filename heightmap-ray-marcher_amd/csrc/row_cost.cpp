@@ -45,8 +45,11 @@ void estimate_row_costs(const DevFrame &f, const double *col_cos_ha, const doubl
 			for (int i = 0; i < 3; ++i) {
 				const double inv = 1.0 / d[i];
 				const double t0 = (f.c0[i] - o[i]) * inv, t1 = (f.c1[i] - o[i]) * inv;
-				lo = std::fmax(lo, std::fmin(t0, t1)); // (fmin/fmax drop a NaN operand)
-				hi = std::fmin(hi, std::fmax(t0, t1));
+				// (plain comparisons: gcc keeps fmin / fmax as libm calls without -ffinite-math-only; a NaN parameter
+				// -- 0 * inf on an axis the ray is parallel to -- just leaves lo / hi as they were)
+				const double a = t0 < t1 ? t0 : t1, b = t0 < t1 ? t1 : t0;
+				lo = a > lo ? a : lo;
+				hi = b < hi ? b : hi;
 			}
 			const double steps = (hi - lo) * inv_step;
 			if (steps > best && std::isfinite(steps)) best = steps;

@@ -49,3 +49,47 @@ def test_grid_pow2_flag(hmrm):
         assert rec["grid_pow2"] == exp, gw
         if exp:
             assert rec["inv_grid_width"] == 1.0 / gw
+
+
+def test_spherical_tables_of_a_4k_camera_filled_on_the_host_pool(hmrm, oracle):
+    """A 3840x2160 spherical camera (BASELINE config C3's) has 12 000 table entries: the library fills them in
+    pieces on its host threads (csrc/host_pool.cpp); every entry must be the glibc value the reference's
+    per-pixel sin / cos calls produce (Spherical.cpp:18-25), whichever thread wrote it -- checked for every row
+    and column against the oracle's rays along the frame's diagonal, its first row and its first column, for
+    several cameras in a row (the pool is reused) and from two caller threads at once."""
+    import threading
+    wl = hmrm.synth.WORKLOADS["C3"]
+    params = wl.scene_params()
+
+    def check(k):
+        cam = wl.camera(k, 64)
+        rec = hmrm.debug_frame(cam, params, wl.map_size, wl.map_size)
+        cfg = oracle.make_cfg(cam, params, wl.map_size, wl.map_size)
+        W, H = cam.width, cam.height
+        for px in range(0, W, 7):
+            _, d, _ = oracle.probe_ray(cfg, px, 1080)
+            got = [rec["row_sin_va"][1080] * rec["col_cos_ha"][px], rec["row_sin_va"][1080] * rec["col_sin_ha"][px]]
+            assert np.array_equal(_bits(got), _bits(d[:2])), (k, px)
+        for py in range(0, H, 5):
+            _, d, _ = oracle.probe_ray(cfg, 17, py)
+            got = [rec["row_sin_va"][py] * rec["col_cos_ha"][17], rec["row_sin_va"][py] * rec["col_sin_ha"][17], rec["row_cos_va"][py]]
+            assert np.array_equal(_bits(got), _bits(d)), (k, py)
+        for px in (0, 1023, 1024, 1499, 1500, 2999, 3000, 3839):  # piece boundaries of 2, 3 and 4 threads and the ends
+            _, d, _ = oracle.probe_ray(cfg, px, 0)
+            got = [rec["row_sin_va"][0] * rec["col_cos_ha"][px], rec["row_sin_va"][0] * rec["col_sin_ha"][px]]
+            assert np.array_equal(_bits(got), _bits(d[:2])), (k, px)
+
+    for k in range(4):
+        check(k)
+    errors = []
+
+    def worker(ks):
+        try:
+            for k in ks:
+                check(k)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+    ts = [threading.Thread(target=worker, args=(range(a, a + 3),)) for a in (10, 20)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors

@@ -607,6 +607,39 @@ def test_two_streams_two_spherical_cameras(gpu, oracle):
     scene.close()
 
 
+def test_moving_spherical_camera_shares_table_halves(gpu, oracle):
+    """A moving spherical camera on one stream, no host sync between frames: the library copies the row tables
+    (sin / cos of va) or the column tables (of ha) from a cached record when only the other half changed
+    (api.cpp prepare_frame), fills the rest on its host pool and uploads with a kernel of the launch stream.
+    Orbit steps (hang and pos change), tilts (vang), both, a translation, a bigger frame in between (the
+    per-stream table arena is re-allocated) and more cameras than the cache has slots: every frame equals the
+    oracle's (Spherical.cpp:17-31)."""
+    import torch
+    rgb, cmap = scenes.small_maps(96, 96, 62)
+    params = gpu.SceneParams.make(0.0, 10.0, grid_width=1.0)
+    scene = gpu.Scene(rgb, cmap, params)
+    heights = oracle.update_heightmap(rgb, params)
+
+    def cam(hang, vang, pos=(-30.0, 30.0, 40.0), W=256, H=144, fov=170.0):
+        return gpu.Camera.make(width=W, height=H, projection=2, hfov=gpu.degrees_to_rads(fov), hang=gpu.degrees_to_rads(hang),
+                               vang=gpu.degrees_to_rads(vang), pos=pos, step_dist=0.25, bg=(5, 6, 7))
+    seq = [cam(-45, 110), cam(-40, 110), cam(-45, 120), cam(-40, 120), cam(-40, 120, pos=(-20.0, 35.0, 44.0)),
+           cam(-45, 110, W=1400, H=900), cam(-45, 110), cam(-40, 120, fov=120.0), cam(-40, 110, fov=120.0)]
+    seq += [cam(-45 + 0.5 * k, 110) for k in range(70)]   # (more than the 64 cached records of a stream)
+    seq += [cam(-45, 100 + 0.25 * k) for k in range(10)] + [cam(-45, 110), cam(-40, 110)]
+    st = torch.cuda.Stream()
+    outs = [torch.zeros((c.height, c.width, 4), dtype=torch.uint8, device="cuda") for c in seq]
+    torch.cuda.synchronize()
+    for c, o in zip(seq, outs):
+        scene.render_rows_device(c, o.data_ptr(), c.width * 4, 0, c.height, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    for i, (c, o) in enumerate(zip(seq, outs)):
+        want = oracle.render(oracle.make_cfg(c, params, 96, 96), heights, cmap)[0]
+        assert np.array_equal(o.cpu().numpy(), want), i
+    assert scene.take_capped(st.cuda_stream) == 0
+    scene.close()
+
+
 def test_two_host_threads_share_one_scene(gpu, oracle):
     """SURVEY 8(b) "Threading": two host threads drive one scene at the same time, each on its own HIP
     stream with its own cameras (spherical and perspective, so per-frame tables are in play); every frame
