@@ -55,8 +55,12 @@ struct Knobs {
 	int64_t step_cap = (int64_t)1 << 26; // HMRM_STEP_CAP
 	int kernel = 0;                      // HMRM_KERNEL: 0 leap, 1 group, 2 simple
 	bool tile_order = true;              // HMRM_TILE_ORDER=0 -> row-major launch order
+	int order_mode = 2;                  // HMRM_TILE_ORDER=1 -> plain rotation; 2 (default) -> rotation, then calibrated from measurement
 	int diag_mode = 0;                   // HMRM_DIAG_ITERS (tools)
 	int min_level = -1;                  // HMRM_MIN_LEVEL (tools)
+	bool order_verbose = false;          // HMRM_ORDER_VERBOSE=1 (tools): report every calibration on stderr
+	int seg_n = 0;                       // HMRM_TILE_SEGMENTS=b0:c0,b1:c1,.. (tools): tile-row pieces to start first, in this order
+	int seg_b[3] = {0, 0, 0}, seg_c[3] = {0, 0, 0};
 };
 
 Knobs read_knobs() {
@@ -69,8 +73,23 @@ Knobs read_knobs() {
 		if (v > 0) k.step_cap = v > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)v;
 	}
 	if (const char *s = getenv("HMRM_KERNEL")) k.kernel = strcmp(s, "simple") == 0 ? 2 : (strcmp(s, "group") == 0 ? 1 : 0);
-	if (const char *s = getenv("HMRM_TILE_ORDER")) k.tile_order = s[0] != '0';
+	if (const char *s = getenv("HMRM_TILE_ORDER")) {
+		k.tile_order = s[0] != '0';
+		if (s[0] == '1' || s[0] == '2') k.order_mode = s[0] - '0';
+	}
 	if (const char *s = getenv("HMRM_DIAG_ITERS")) k.diag_mode = atoi(s);
+	if (const char *s = getenv("HMRM_ORDER_VERBOSE")) k.order_verbose = s[0] == '1';
+	if (const char *s = getenv("HMRM_TILE_SEGMENTS")) {
+		int b = 0, c = 0, used = 0;
+		while (k.seg_n < 3 && sscanf(s, "%d:%d%n", &b, &c, &used) == 2 && b >= 0 && c > 0) {
+			k.seg_b[k.seg_n] = b;
+			k.seg_c[k.seg_n] = c;
+			++k.seg_n;
+			s += used;
+			if (*s != ',') break;
+			++s;
+		}
+	}
 	if (const char *s = getenv("HMRM_MIN_LEVEL"))
 		if (s[0] >= '0' && s[0] < '0' + hmrm::kMipLevels) k.min_level = s[0] - '0';
 	return k;
@@ -80,6 +99,7 @@ Knobs read_knobs() {
 
 constexpr int kCostRows = 16; // one sample row per 16-row tile row (render_tile_shape)
 constexpr int kFrameSlots = 64;  // cached per-frame records (and spherical tables) per stream: a 64-frame orbit fits
+constexpr int kMaxMeasRows = 512;  // tile rows (8192 frame rows) a launch order is calibrated for; taller frames keep the rotation
 constexpr int kMaxStreamCtx = 32; // streams a scene keeps launch state for (more: the least recently used one is recycled, with a stream sync)
 
 // One cached per-frame record: the result of the host set-up (camera.cpp) for one camera, and for
@@ -96,6 +116,15 @@ struct FrameSlot {
 	double *d_tables = nullptr;  // spherical sin/cos tables: this slot's piece of the context's arenas
 	double *h_tables = nullptr;  // pinned staging, likewise
 	hipEvent_t uploaded = nullptr; // after the H2D copy out of h_tables: the host may rewrite them then
+	// Launch order calibrated by measurement (calibrate_order below).  order_state: 0 rotation, nothing measured;
+	// 1 a measured launch under the rotation is in flight; 2 a measured launch under the candidate order is in
+	// flight; 3 settled (order_n pieces, 0 = the rotation stays).
+	int order_state = 0;
+	uint32_t uses = 0;             // full-frame launches of this record
+	int order_n = 0, order_b[3] = {0, 0, 0}, order_c[3] = {0, 0, 0};
+	double base_makespan = 0.0;    // measured under the rotation (ticks)
+	int meas_rows = 0;             // tile rows of the measured launch in flight
+	hipEvent_t measured = nullptr; // after the read-back of a measured launch
 };
 
 // Everything a launch mutates, per HIP stream: launches on different streams of one scene never
@@ -108,6 +137,10 @@ struct StreamCtx {
 	// otherwise cost a hipMalloc + hipHostMalloc, ~0.1 ms each, in the middle of a sequence of frames)
 	double *d_arena = nullptr, *h_arena = nullptr;
 	double *h_arena_dev = nullptr; // the pinned arena as the device sees it (the upload kernel reads it)
+	// calibration records (allocated with the first measured launch): the device buffer of the ONE measured launch a
+	// context has in flight at a time, and per slot kMaxMeasRows x {start, longest wave} in pinned memory
+	unsigned long long *d_meas = nullptr, *h_meas = nullptr, *h_meas_dev = nullptr;
+	FrameSlot *meas_owner = nullptr; // the slot whose measured launch uses d_meas (until its event is done)
 	size_t arena_n = 0; // doubles per slot
 	// [0] steps [1] hits [2] capped rays (cumulative, never reset) [4..7] traversal diagnostics
 	unsigned long long *d_counters = nullptr;
@@ -144,7 +177,7 @@ struct hmrm_scene {
 	double thr_max_bil = 0.0; // whole-map bound of the interpolated thresholds (bilinear mode)
 	bool bil_valid = false;
 	float *d_mipbuf_bil = nullptr; // the same over the 3x3-dilated table (bilinear quality mode)
-	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/16/64/256-cell windows every 2/8/32/128 cells
+	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/8/../256-cell windows every 2/4/../128 cells
 	int32_t mip_w[hmrm::kMipLevels] = {}, mip_h[hmrm::kMipLevels] = {};
 	int32_t mip_row = 0, mip_plane_shift = 0; // plane layout of both pyramids, see DevFrame
 	size_t mip_floats() const { return (size_t)(hmrm::kMipLevels + 1) << mip_plane_shift; }
@@ -176,8 +209,12 @@ namespace {
 
 void destroy_ctx(StreamCtx *c) {
 	if (!c) return;
-	for (FrameSlot &sl : c->slots)
+	for (FrameSlot &sl : c->slots) {
 		if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+		if (sl.measured) (void)hipEventDestroy(sl.measured);
+	}
+	if (c->d_meas) (void)hipFree(c->d_meas);
+	if (c->h_meas) (void)hipHostFree(c->h_meas);
 	if (c->d_arena) (void)hipFree(c->d_arena);
 	if (c->h_arena) (void)hipHostFree(c->h_arena);
 	if (c->d_counters) (void)hipFree(c->d_counters);
@@ -250,6 +287,137 @@ int choose_tile_rot(const hmrm_scene *s, const std::vector<float> &row_cost, con
 	return 0;
 }
 
+// ---- launch order from measurement ----------------------------------------------------------------------------
+// What decides how long a launch outlives its dispatch is which marching tile rows are handed out LAST: their
+// longest wave runs on after everything else has drained (tools/timeline.py: on C3 the bottom rows of the frame hold
+// steep rays whose waves keep all lanes busy in both blocks of every loop trip and run 60 us, the middle rows 40 us,
+// the horizon rows up to 130 us).  An estimate of a row's march length says nothing about that, so it is MEASURED:
+// the second full-frame launch of a cached camera runs with RowMap::measure set and every wave folds its start time
+// and duration into its tile row's record.  From the records: dispatch time of every tile row under the rotation
+// (D[i] = start of the next row - start of this one) and its longest wave q[i].  Handing the rows out in another
+// order moves their start times by the D of the rows put in front, and the launch lasts max_i (start'_i + q_i): the
+// classic delivery-time problem, best solved by "longest q first".  With the three contiguous pieces the kernel's
+// row map offers that means: head [h0, a) first (the horizon rows, as with the rotation), then the tail [b, end),
+// then the middle [a, b) -- a and b chosen by exhaustive search over the model.  The third launch runs that
+// candidate, measured again, and whichever order had the shorter measured makespan is kept.  Scheduling only.
+double measured_makespan(const unsigned long long *rec, int tiles_y) {
+	unsigned long long s0 = ~0ull;
+	for (int t = 0; t < tiles_y; ++t)
+		if (rec[2 * t]) s0 = std::min(s0, rec[2 * t]);
+	double m = 0.0;
+	for (int t = 0; t < tiles_y; ++t)
+		if (rec[2 * t]) m = std::max(m, (double)(rec[2 * t] - s0) + (double)rec[2 * t + 1]);
+	return m;
+}
+
+// -> number of pieces (0: keep the rotation); records measured under the rotation by `rot`.
+int plan_order_from_measurement(const unsigned long long *rec, int tiles_y, int rot, int *pb, int *pc) {
+	if (tiles_y < 12 || rot < 0 || rot >= tiles_y) return 0;
+	unsigned long long s0 = ~0ull;
+	for (int t = 0; t < tiles_y; ++t) {
+		if (rec[2 * t] == 0ull) return 0; // a tile row without a record: not a launch this plan understands
+		s0 = std::min(s0, rec[2 * t]);
+	}
+	const int N = tiles_y;
+	std::vector<double> st((size_t)N), q((size_t)N), D((size_t)N);
+	double qmax = 0.0;
+	for (int i = 0; i < N; ++i) {
+		const int t = (rot + i) % N;
+		st[(size_t)i] = (double)(rec[2 * t] - s0);
+		if (i > 0) st[(size_t)i] = std::max(st[(size_t)i], st[(size_t)i - 1]); // (rows start in order; noise aside)
+		q[(size_t)i] = (double)rec[2 * t + 1];
+		qmax = std::max(qmax, q[(size_t)i]);
+	}
+	for (int i = 0; i + 1 < N; ++i) D[(size_t)i] = st[(size_t)i + 1] - st[(size_t)i];
+	D[(size_t)N - 1] = N > 1 ? D[(size_t)N - 2] : 0.0;
+	// hot range in dispatch order: up to the last row (before the frame's end) whose longest wave matters
+	int n = 0;
+	for (int i = 0; i < N - rot; ++i)
+		if (q[(size_t)i] >= 0.05 * qmax) n = i + 1;
+	if (n < 12) return 0;
+	// Two objectives.  PRIMARY: the modelled makespan max_i (start'_i + q_i).  Rows whose longest wave alone nearly
+	// fills the launch (the horizon rows: q >= 0.85 of the measured makespan) bound it from below whatever the order, and
+	// in practice even they finish earlier when less is left running beside them at the end -- which the model, with
+	// its fixed q, cannot see.  So the search minimises the SECONDARY objective, the same maximum over all other rows,
+	// among the orders that do not make the primary one worse; the measured third launch has the last word.
+	std::vector<double> cum((size_t)n + 1, 0.0), g((size_t)n), g2((size_t)n), pm((size_t)n + 1, 0.0), sm((size_t)n + 1, -1e300),
+	    pm2((size_t)n + 1, 0.0), sm2((size_t)n + 1, -1e300);
+	double floor_ms = 0.0; // everything after the hot range starts after it whatever its internal order
+	for (int i = n; i < N; ++i) floor_ms = std::max(floor_ms, st[(size_t)i] + q[(size_t)i]);
+	double span = floor_ms;
+	for (int i = 0; i < n; ++i) span = std::max(span, st[(size_t)i] + q[(size_t)i]);
+	for (int i = 0; i < n; ++i) {
+		cum[(size_t)i + 1] = cum[(size_t)i] + D[(size_t)i];
+		g[(size_t)i] = cum[(size_t)i] + q[(size_t)i];
+		g2[(size_t)i] = q[(size_t)i] >= 0.85 * span ? -1e300 : g[(size_t)i];
+		pm[(size_t)i + 1] = std::max(pm[(size_t)i], g[(size_t)i]);
+		pm2[(size_t)i + 1] = std::max(pm2[(size_t)i], g2[(size_t)i]);
+	}
+	for (int i = n - 1; i >= 0; --i) {
+		sm[(size_t)i] = std::max(sm[(size_t)i + 1], g[(size_t)i]);
+		sm2[(size_t)i] = std::max(sm2[(size_t)i + 1], g2[(size_t)i]);
+	}
+	const double base = std::max(pm[(size_t)n], floor_ms), base2 = std::max(pm2[(size_t)n], 0.0);
+	double best2 = base2;
+	int best_a = 0, best_b = 0;
+	const int step = std::max(1, n / 96);
+	for (int a = 0; a < n; a += step) {
+		double mid = -1e300, mid2 = -1e300; // max of g / g2 over [a, b)
+		int scanned = a;
+		for (int b2 = a + step; b2 < n; b2 += step) {
+			for (; scanned < b2; ++scanned) {
+				mid = std::max(mid, g[(size_t)scanned]);
+				mid2 = std::max(mid2, g2[(size_t)scanned]);
+			}
+			const double shift_tail = cum[(size_t)a] - cum[(size_t)b2], shift_mid = cum[(size_t)n] - cum[(size_t)b2];
+			const double m1 = std::max(std::max(pm[(size_t)a], sm[(size_t)b2] + shift_tail), std::max(mid + shift_mid, floor_ms));
+			if (m1 > 1.001 * base) continue;
+			const double m2 = std::max(pm2[(size_t)a], std::max(sm2[(size_t)b2] + shift_tail, mid2 + shift_mid));
+			if (m2 < best2) {
+				best2 = m2;
+				best_a = a;
+				best_b = b2;
+			}
+		}
+	}
+	if (!(best2 < 0.95 * base2) || best_b <= best_a) return 0;
+	int k = 0;
+	if (best_a > 0) { pb[k] = rot; pc[k] = best_a; ++k; }
+	pb[k] = rot + best_b; pc[k] = n - best_b; ++k;
+	pb[k] = rot + best_a; pc[k] = best_b - best_a; ++k;
+	return k;
+}
+
+// RowMap's launch order from up to three contiguous tile-row pieces that start first, in the order given (they must
+// be disjoint and form one contiguous range of tile rows), followed by the rest of the frame from the end of that
+// range onwards, wrapping around.  No pieces = plain rotation by `rot`.
+void set_tile_order(hmrm::RowMap *r, int tiles_y, int rot, int n, const int *b, const int *c) {
+	for (int k = 0; k < 3; ++k) r->seg_first[k] = 0x7fffffff;
+	for (int k = 0; k < 4; ++k) r->seg_delta[k] = 0;
+	r->seg_delta[0] = rot;
+	if (n <= 0 || tiles_y >= 32768) return;
+	int lo = tiles_y, hi = 0, total = 0;
+	for (int k = 0; k < n; ++k) {
+		if (b[k] < 0 || c[k] <= 0 || b[k] + c[k] > tiles_y) return;
+		for (int j = 0; j < k; ++j)
+			if (b[k] < b[j] + c[j] && b[j] < b[k] + c[k]) return; // overlap
+		lo = std::min(lo, b[k]);
+		hi = std::max(hi, b[k] + c[k]);
+		total += c[k];
+	}
+	if (hi - lo != total) return; // not one contiguous range
+	int first = 0;
+	for (int k = 0; k < n; ++k) {
+		if (k > 0) r->seg_first[k - 1] = first;
+		r->seg_delta[k] = b[k] - first;
+		first += c[k];
+	}
+	if (total < tiles_y) { // the rest: from `hi` on, wrapping
+		r->seg_first[n - 1] = first;
+		r->seg_delta[n] = hi - first;
+	}
+}
+
 int check_camera(const hmrm_camera *cam) {
 	if (!cam) return fail(HMRM_E_ARG, "camera is NULL");
 	if (cam->width <= 0 || cam->height <= 0) return fail(HMRM_E_ARG, "resolution must be positive");
@@ -300,6 +468,10 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 				if (!sl.valid) break;
 			}
 		slot->valid = false;
+		if (slot->order_state == 1 || slot->order_state == 2) HIP_TRY(hipEventSynchronize(slot->measured)); // (its records are about to be reused)
+		slot->order_state = 0;
+		slot->uses = 0;
+		slot->order_n = 0;
 		hmrm::HostCamera hc;
 		to_host_camera(cam, &hc);
 		double *cc = nullptr, *cs = nullptr, *rs = nullptr, *rc = nullptr;
@@ -415,10 +587,73 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 // groups + exact leaps), "group" (speculative groups only), "simple" (the literal
 // one-step-at-a-time loop, kept for A/B runs and as an in-library cross-check).  All produce
 // identical pixels and counts.
-int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const FrameSlot *slot, const hmrm::RowMap &rows,
+int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot *slot, const hmrm::RowMap &rows,
                  uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats) {
 	hmrm::RowMap rows_in_order = rows;
-	rows_in_order.tile_rot = choose_tile_rot(s, slot->row_cost, rows);
+	bool measure_now = false;
+	int tiles_y = 0;
+	{
+		int tile_w = 1, tile_h = 1;
+		hmrm::render_tile_shape(&tile_w, &tile_h);
+		tiles_y = (rows.local_rows + tile_h - 1) / tile_h;
+		const bool pieces = s->knobs.seg_n > 0 && rows.band_rows == 0 && rows.row_begin == 0;
+		const int rot = choose_tile_rot(s, slot->row_cost, rows);
+		int nb = pieces ? s->knobs.seg_n : 0, b[3] = {s->knobs.seg_b[0], s->knobs.seg_b[1], s->knobs.seg_b[2]},
+		    c3[3] = {s->knobs.seg_c[0], s->knobs.seg_c[1], s->knobs.seg_c[2]};
+		// calibration (see plan_order_from_measurement): full frames of the production kernel only
+		const bool eligible = !pieces && !stats && s->knobs.tile_order && s->knobs.order_mode == 2 && s->knobs.kernel != 2 &&
+		                      rows.band_rows == 0 && rows.row_begin == 0 && rows.local_rows == f.screen_h && tiles_y >= 12 &&
+		                      tiles_y <= kMaxMeasRows && s->map_w < (1 << 24) && s->map_h < (1 << 24);
+		if (eligible) {
+			++slot->uses;
+			const size_t idx = (size_t)(slot - c->slots);
+			unsigned long long *h_rec = c->h_meas ? c->h_meas + idx * 2 * kMaxMeasRows : nullptr;
+			if ((slot->order_state == 1 || slot->order_state == 2) && slot->meas_rows == tiles_y &&
+			    hipEventQuery(slot->measured) == hipSuccess) {
+				if (slot->order_state == 1) {
+					slot->base_makespan = measured_makespan(h_rec, tiles_y);
+					slot->order_n = plan_order_from_measurement(h_rec, tiles_y, rot, slot->order_b, slot->order_c);
+					slot->order_state = slot->order_n > 0 ? 10 : 3; // 10: candidate ready, to be measured by this launch
+					if (s->knobs.order_verbose) {
+						fprintf(stderr, "hmrm order: rotation %d of %d tile rows measured, makespan %.1f us; candidate:", rot, tiles_y, slot->base_makespan / 100.0);
+						for (int k = 0; k < slot->order_n; ++k) fprintf(stderr, " [%d,%d)", slot->order_b[k], slot->order_b[k] + slot->order_c[k]);
+						fprintf(stderr, "%s\n", slot->order_n ? "" : " none (the model predicts < 3 % gain)");
+					}
+				} else {
+					const double got = measured_makespan(h_rec, tiles_y);
+					if (!(got < 0.99 * slot->base_makespan)) slot->order_n = 0; // the rotation stays
+					slot->order_state = 3;
+					if (s->knobs.order_verbose)
+						fprintf(stderr, "hmrm order: candidate measured, makespan %.1f us against %.1f us: %s\n", got / 100.0,
+						        slot->base_makespan / 100.0, slot->order_n ? "kept" : "dropped");
+				}
+			}
+			// (one measured launch per context at a time: they share the device records)
+			if (c->meas_owner && (c->meas_owner->order_state == 3 || c->meas_owner->order_state == 0 ||
+			                      hipEventQuery(c->meas_owner->measured) == hipSuccess))
+				c->meas_owner = nullptr;
+			const bool free_records = c->meas_owner == nullptr;
+			if (slot->order_state == 0 && slot->uses >= 2 && free_records) measure_now = true; // -> 1
+			if (slot->order_state == 10 && free_records) measure_now = true;                    // -> 2
+			if (slot->order_state == 10 || slot->order_state == 2 || slot->order_state == 3) {
+				nb = slot->order_n;
+				for (int k = 0; k < nb; ++k) { b[k] = slot->order_b[k]; c3[k] = slot->order_c[k]; }
+			}
+		}
+		set_tile_order(&rows_in_order, tiles_y, rot, nb, b, c3);
+	}
+	if (measure_now) {
+		if (!c->d_meas) {
+			HIP_TRY(hipMalloc((void **)&c->d_meas, (size_t)kMaxMeasRows * hmrm::kMeasureStride * sizeof(unsigned long long)));
+			const size_t n = (size_t)kFrameSlots * 2 * kMaxMeasRows * sizeof(unsigned long long);
+			HIP_TRY(hipHostMalloc((void **)&c->h_meas, n, hipHostMallocMapped));
+			HIP_TRY(hipHostGetDevicePointer((void **)&c->h_meas_dev, c->h_meas, 0));
+		}
+		if (!slot->measured) HIP_TRY(hipEventCreateWithFlags(&slot->measured, hipEventDisableTiming));
+		rows_in_order.measure = c->d_meas;
+		c->meas_owner = slot;
+		HIP_TRY(hmrm::launch_measure_init(rows_in_order.measure, tiles_y, c->stream));
+	}
 	// the production kernel indexes cells and windows with 24-bit multiplies (leap_common.hpp index_2d): a map
 	// with a side of 2^24 cells or more (then at most 32 cells the other way) goes through the literal loop
 	const bool huge_side = s->map_w >= (1 << 24) || s->map_h >= (1 << 24);
@@ -430,6 +665,13 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const Fra
 		const bool leap = s->knobs.kernel != 1;
 		HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
 		                                 c->d_counters, d_steps, d_entry, stats, leap, c->stream));
+	}
+	if (measure_now) {
+		const size_t idx = (size_t)(slot - c->slots);
+		HIP_TRY(hmrm::launch_measure_readback(rows_in_order.measure, c->h_meas_dev + idx * 2 * kMaxMeasRows, tiles_y, c->stream));
+		HIP_TRY(hipEventRecord(slot->measured, c->stream));
+		slot->meas_rows = tiles_y;
+		slot->order_state = slot->order_state == 10 ? 2 : 1;
 	}
 	// (only streams other than the scene's own can be recycled, ctx_for)
 	if (c->stream != s->stream) HIP_TRY(hipEventRecord(c->last_launch, c->stream));
@@ -703,7 +945,7 @@ static int render_common(hmrm_scene *s, const hmrm_camera *cam, uint8_t *rgba, s
 	hmrm::DevFrame f;
 	FrameSlot *slot = nullptr;
 	if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
-	hmrm::RowMap rows{0, cam->height, 0, 0, 1, 0};
+	hmrm::RowMap rows{0, cam->height, 0, 0, 1, {}, {}, nullptr};
 	if (want_stats) {
 		HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), s->stream));
 		HIP_TRY(hipMemsetAsync(c->d_counters + 4, 0, 4 * sizeof(unsigned long long), s->stream));
@@ -845,7 +1087,7 @@ int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_ca
 		hmrm::DevFrame f;
 		FrameSlot *slot = nullptr;
 		if ((rc2 = prepare_frame(s, c, cam, &f, &slot))) return rc2;
-		hmrm::RowMap rows{0, local, kBand, i, n, 0};
+		hmrm::RowMap rows{0, local, kBand, i, n, {}, {}, nullptr};
 		if ((rc2 = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc2;
 		// band b of this scene's strip is frame rows [(i + b*n) * kBand, ...): contiguous in both
 		for (int b = 0; (i + b * n) * kBand < H; ++b) {
@@ -950,7 +1192,7 @@ int hmrm_render_begin(const hmrm_scene *scene, const hmrm_camera *cam, int32_t *
 	hmrm::DevFrame f;
 	FrameSlot *slot = nullptr;
 	if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
-	hmrm::RowMap rows{0, cam->height, 0, 0, 1, 0};
+	hmrm::RowMap rows{0, cam->height, 0, 0, 1, {}, {}, nullptr};
 	if ((rc = launch_frame(s, c, f, slot, rows, r->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;
 	HIP_TRY(hipEventRecord(r->kernel_done, s->stream));
 	HIP_TRY(hipStreamWaitEvent(s->copy_stream, r->kernel_done, 0));
@@ -1024,7 +1266,7 @@ double hmrm_bench_kernel_ms(const hmrm_scene *scene, const hmrm_camera *cam, int
 		hmrm::DevFrame f;
 		FrameSlot *slot = nullptr;
 		if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
-		hmrm::RowMap rows{0, cam->height, 0, 0, 1, 0};
+		hmrm::RowMap rows{0, cam->height, 0, 0, 1, {}, {}, nullptr};
 		HIP_TRY(hipEventRecord(s->ev0, s->stream));
 		for (int i = 0; i < iters; ++i)
 			if ((rc = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;

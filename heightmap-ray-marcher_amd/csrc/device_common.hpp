@@ -237,6 +237,7 @@ constexpr int kBlockThreads = 64 * kWavesX * kWavesY;
 constexpr int kTileW = kWavesX * kWaveW, kTileH = kWavesY * kWaveH;
 struct PixelId {
 	int px, py, lrow;
+	int tile_y; // tile row of the launch this workgroup renders (wave-uniform)
 	bool live;
 };
 // Frame row of local row `lrow` of the launch's output (contiguous strip or cyclic bands).
@@ -250,16 +251,20 @@ __device__ __forceinline__ int frame_row_of(const RowMap &rows, int lrow) {
 
 __device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap &rows, int tiles_y) {
 	// Grid of tiles: x = tile column (fastest, so workgroups still start row by row), y (+ z for
-	// frames taller than 32768 tile rows) = tile row; the rows are rotated so that the costliest
-	// ones start first (RowMap::tile_rot, in tile rows).  No integer division per wave.
+	// frames taller than 32768 tile rows) = grid row; grid rows are handed to tile rows piece by piece so that the
+	// costliest tile rows start first (RowMap::seg_first / seg_delta).  Scalar work, no integer division per wave.
 	const int tile_x = (int)blockIdx.x;
-	unsigned ty = blockIdx.z * 32768u + blockIdx.y;
-	const bool row_exists = ty < (unsigned)tiles_y; // (the last z-slab may be partly empty)
-	ty += (unsigned)rows.tile_rot;
+	const unsigned gy = blockIdx.z * 32768u + blockIdx.y;
+	const bool row_exists = gy < (unsigned)tiles_y; // (the last z-slab may be partly empty)
+	int delta = rows.seg_delta[0];
+#pragma unroll
+	for (int k = 1; k < kOrderSegs; ++k) delta = gy >= (unsigned)rows.seg_first[k - 1] ? rows.seg_delta[k] : delta;
+	unsigned ty = gy + (unsigned)delta;
 	if (ty >= (unsigned)tiles_y) ty -= (unsigned)tiles_y;
 	const int tile_y = (int)ty;
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	PixelId p;
+	p.tile_y = row_exists ? tile_y : -1;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	p.px = tile_x * kTileW + (wave % kWavesX) * kWaveW + (lane % kWaveW);
 	p.lrow = tile_y * kTileH + (wave / kWavesX) * kWaveH + (lane / kWaveW);
 	p.py = frame_row_of(rows, p.lrow);

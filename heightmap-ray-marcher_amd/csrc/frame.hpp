@@ -40,7 +40,7 @@ struct DevFrame {
 	double thr_max;              // max over cells of heightmap_buf[i] + c0.z (informational; the kernel uses the pyramid's top plane)
 	int64_t step_cap;            // guard for the reference's unbounded while(true) (:1000)
 	// window-maximum pyramid over the thr table (render_fast.hip): level l holds the maximum
-	// of thr (NaN ignored: z < NaN never hits) over S x S-cell windows, S = 4, 16, 64, 256,
+	// of thr (NaN ignored: z < NaN never hits) over S x S-cell windows, S = 4, 8, 16, .. 256,
 	// placed every S/2 cells; floats rounded up.  One buffer of kMipLevels + 1 planes of
 	// 1 << mip_plane_shift floats: window (ix, iy) of level l is element
 	// (l << mip_plane_shift) + iy * mip_row + ix -- every level uses level 0's row pitch, so the
@@ -67,10 +67,11 @@ struct DevFrame {
 	int32_t pad4_;
 };
 
-// Window sizes S = 4 * 2^(kLevelStep*l) cells, placed every S/2 cells.  kLevelStep 2: S = 4, 16, 64, 256;
-// kLevelStep 1: S = 4, 8, 16, 32, 64, 128, 256.
+// Window sizes S = 4 * 2^(kLevelStep*l) cells, placed every S/2 cells.  kLevelStep 1 (the build): S = 4, 8, 16, 32,
+// 64, 128, 256 -- a ray moves two levels at a time (4, 16, 64, 256) until it has made a few jumps and then one at a time
+// (render_fast.hip kAdaptAfter); kLevelStep 2: only S = 4, 16, 64, 256 exist (round 2's pyramid, kept for A/B runs).
 #ifndef HMRM_LEVEL_STEP
-#define HMRM_LEVEL_STEP 2
+#define HMRM_LEVEL_STEP 1
 #endif
 constexpr int kLevelStep = HMRM_LEVEL_STEP;
 #ifndef HMRM_MIP_LEVELS
@@ -91,8 +92,19 @@ struct RowMap {
 	int32_t local_rows;    // rows held by the output buffer
 	int32_t band_rows;     // 0 = contiguous; else cyclic bands of this many rows
 	int32_t band_index, band_count;
-	int32_t tile_rot;      // launch order: grid row j renders tile row (j + tile_rot) mod tile rows (api.cpp)
+	// Launch order (api.cpp choose_tile_order): the grid's rows are handed out to tile rows in up to kOrderSegs
+	// contiguous pieces.  Grid row j belongs to the last piece k with j >= seg_first[k] (seg_first[0] = 0 is
+	// implicit; unused pieces have seg_first = INT32_MAX) and renders tile row (j + seg_delta[k]) mod tile rows --
+	// the last piece may wrap around the end of the frame.  Together the pieces cover every tile row once.
+	int32_t seg_first[3];  // pieces 1..3
+	int32_t seg_delta[4];  // pieces 0..3
+	// Calibration launch (api.cpp, launch order from measurement): when not null, every wave folds its duration, and
+	// a tile row's first wave its start time (s_memrealtime ticks, 10 ns), into the row's record: kMeasureStride words
+	// per tile row (render_fast.hip).  Scheduling aid only.
+	unsigned long long *measure;
 };
+constexpr int kMeasureStride = 33;
+constexpr int kOrderSegs = 4;
 
 // Host: fill everything except the table pointers / thr_max / step_cap.
 // Also fills the spherical tables (host arrays of screen_w / screen_h doubles) when

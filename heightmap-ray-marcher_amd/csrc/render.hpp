@@ -49,6 +49,12 @@ void render_tile_shape(int *tile_w, int *tile_h);
 // GetRay + distance() of pixel (px,py): d_out7 = pos[3], dir[3], d.
 hipError_t launch_probe(const DevFrame &f, int px, int py, double *d_out7, hipStream_t stream);
 
+// Launch-order calibration (RowMap::measure): device records of tile_rows x kMeasureStride words, zeroed before a
+// measured launch and reduced afterwards to {start of the row's first workgroup, longest wave of the row} per tile row
+// in pinned (device-mapped) host memory -- both small kernels of the launch stream.
+hipError_t launch_measure_init(unsigned long long *d_rec, int tile_rows, hipStream_t stream);
+hipError_t launch_measure_readback(const unsigned long long *d_rec, unsigned long long *h_pinned_dev, int tile_rows, hipStream_t stream);
+
 // n doubles from pinned (device-mapped) host memory into device memory, as a kernel on `stream` (render.hip).
 hipError_t launch_upload_tables(const double *h_pinned, double *d_dst, size_t n, hipStream_t stream);
 

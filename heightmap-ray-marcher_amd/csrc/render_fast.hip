@@ -27,9 +27,13 @@
 //     steps: each was inside the grid, so the reference executed its height load there.
 //
 // Pyramid layout (built by k_build_mip*): level l holds maxima of S x S-cell windows,
-// S = 4, 16, 64, 256, placed every S/2 cells (overlapping), so that a ray can always pick
+// S = 4, 8, 16, .. 256, placed every S/2 cells (overlapping), so that a ray can always pick
 // a window in which it has at least S/2 cells of room ahead.  Values are floats
 // rounded UP (a larger bound is always safe).  Above them: the whole map, the one window of a top plane.
+#ifdef HMRM_TIMELINE
+#include <cstdio>
+#include <cstdlib>
+#endif
 #include "device_common.hpp"
 #include "leap_common.hpp"
 #include "leap_diag.hpp"
@@ -53,6 +57,17 @@ constexpr int kMinLeap = HMRM_MIN_LEAP; // a jump shorter than this is not worth
 #define HMRM_UP_RATIO (kLevelStep == 2 ? 4.0 : 2.0)
 #endif
 constexpr double kUpRatio = HMRM_UP_RATIO; // see the level policy in k_render_fast
+// Per-ray adaptive level spacing (pyramids with windows doubling per level, HMRM_LEVEL_STEP=1): a ray moves two
+// levels at a time -- windows of 4, 16, 64, 256 cells, which is what ordinary rays want (fewer level changes) --
+// until it has made more than HMRM_ADAPT_AFTER successful jumps; from then on one level at a time, so that the few
+// long rays skimming the terrain (the launch's tail) can use the 8-, 32- and 128-cell windows in between: where a
+// 16-cell window clears the ray and the 64-cell one does not, the 32-cell one often does and the jump doubles.
+// 0 = off (every ray one level at a time).  Performance only: any level sequence gives the same pixels.
+#ifndef HMRM_ADAPT_AFTER
+#define HMRM_ADAPT_AFTER 8
+#endif
+constexpr int kAdaptAfter = (kLevelStep == 1) ? HMRM_ADAPT_AFTER : 0;
+constexpr bool kAdaptive = kAdaptAfter > 0;
 
 // ---- bilinear quality mode (HMRM_BILINEAR; a build-side addition, not in the reference) ----
 // Same definition, operation for operation, as oracle/hmrm_oracle.c "bilinear quality mode":
@@ -102,6 +117,14 @@ __device__ __forceinline__ uint32_t shade_hit_bilinear(const DevFrame &f, const 
 
 } // namespace
 
+// Tool build only (-DHMRM_TIMELINE, tools/timeline.py): every wave of the production (non-instrumented) kernel
+// stores its start and end time (s_memtime) and the XCD it ran on into pinned host memory; the library writes
+// the last launch's records to $HMRM_TIMELINE_FILE when the process ends.  Not compiled into the product.
+#ifdef HMRM_TIMELINE
+struct TimelineRec { unsigned long long t0, t1; unsigned int xcc, pad; };
+__device__ TimelineRec *g_timeline = nullptr;
+#endif
+
 #ifndef HMRM_MIN_WAVES
 #define HMRM_MIN_WAVES 1
 #endif
@@ -121,6 +144,12 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
 	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
 	const PixelId pid = pixel_of_lane(f, rows, tiles_y);
+#ifdef HMRM_TIMELINE
+	const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+	// calibration launches only (RowMap::measure): when did this wave start
+	unsigned long long wave_t0 = 0;
+	if (!STATS && rows.measure) wave_t0 = __builtin_amdgcn_s_memrealtime();
 	LoopDiag<STATS> diag; // (empty unless STATS: leap_diag.hpp)
 	diag.start();
 	unsigned long long my_steps = 0;
@@ -168,10 +197,11 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 				const double descent = (z - f.c0[2]) * __builtin_amdgcn_rcp(-sz); // steps down to min_height
 				const double lateral = descent * __builtin_fmax(__builtin_fabs(sx), __builtin_fabs(sy)) * (GWM == 0 ? 1.0 : f.inv_grid_width);
 #pragma unroll
-				for (int l = kMipLevels - 1; l >= 0; --l) // windows every 1 << hs cells: at least that much room ahead
+				for (int l = kMipLevels - 1; l >= 0; l -= (kAdaptive ? 2 : 1)) // windows every 1 << hs cells: at least that much room ahead
 					lev = (l >= f.min_level && lateral <= (double)(1 << (kLevelStep * l + 1))) ? l : lev;
 			}
 			int cooldown = 0, fails = 0;
+			int jumps = 0; // successful jumps so far (kAdaptive)
 			Axis ax, ay, az;
 			ax.key = ay.key = az.key = 0xfffffffeu; // never matches: forces the first refresh
 			ax.delta = ay.delta = az.delta = 0.0;
@@ -277,13 +307,17 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						//                                        growing pause while attempts keep failing
 						const bool binade_bound = room_b <= room;
 						const bool height_limited = inb0 && exact && (!above || z_bound);
-						const int coarser = lev >= kMipLevels - 1 ? kMipLevels - 1 : lev + 1;
+						// levels per move: two while the ray is young (kAdaptive), then one
+						const bool young = kAdaptive && jumps <= kAdaptAfter;
+						const int lstep = kAdaptive ? (young ? 2 : 1) : 1;
+						if (kAdaptive) jumps += ok ? 1 : 0;
+						const int coarser = lev + lstep > kMipLevels - 1 ? kMipLevels - 1 : lev + lstep;
 						const int minlev = f.min_level;
 #ifndef HMRM_DOWN
 #define HMRM_DOWN 1
 #endif
 						// a failed height test drops HMRM_DOWN levels, a height-limited jump one
-						const int drop = ok ? 1 : HMRM_DOWN;
+						const int drop = (ok ? 1 : HMRM_DOWN) * lstep;
 						const int finer = top ? kMipLevels - 1 : (lev - drop > minlev ? lev - drop : minlev);
 						const bool at_finest = lev == minlev;
 						// (selects, not branches: the three cases are mutually exclusive)
@@ -291,7 +325,9 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						const bool hl = !crossed && height_limited;
 						const bool other = !crossed && !hl;
 						// (lane-mask logic: `a ? b : c` on booleans would be materialised in VGPRs)
-						const bool go_up = (crossed & (room_z >= kUpRatio * room) & !binade_bound) | other;
+						// (a window lstep levels up is 2^lstep times as long: the scaling rides on the exponent)
+						const double room_up = kAdaptive ? __builtin_ldexp(room, lstep) : kUpRatio * room;
+						const bool go_up = (crossed & (room_z >= room_up) & !binade_bound) | other;
 						const int fails_before = fails;
 						lev = hl ? finer : (go_up ? coarser : lev);
 						fails = (crossed | (hl & ok)) ? 0 : fails + (other ? 1 : 0);
@@ -430,6 +466,22 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 	}
 	publish_counters<STATS>(st, my_steps, my_hit, my_cap);
 	diag.publish(st, f);
+	if (!STATS && rows.measure && pid.tile_y >= 0 && (threadIdx.x & 63) == 0) {
+		// record of a tile row: [0] start of its first workgroup (rows are handed out left to right), [1 + k] longest
+		// wave among the tile columns = k mod 32 (32 addresses per row: the atomics of a row's 2 x 480 waves spread out)
+		const unsigned long long took = __builtin_amdgcn_s_memrealtime() - wave_t0;
+		unsigned long long *rec = rows.measure + (size_t)pid.tile_y * kMeasureStride;
+		if (blockIdx.x == 0 && threadIdx.x == 0) rec[0] = wave_t0;
+		atomicMax(&rec[1 + (blockIdx.x & 31u)], took);
+	}
+#ifdef HMRM_TIMELINE
+	if (!STATS && g_timeline && (threadIdx.x & 63) == 0) {
+		unsigned xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		const size_t wave = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (kBlockThreads / 64) + (threadIdx.x >> 6);
+		g_timeline[wave] = TimelineRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), xcc, 0u};
+	}
+#endif
 }
 
 // ---------------------------------------------------------------- pyramid ----
@@ -573,6 +625,31 @@ static void launch_proj(bool leap, const DevFrame &f, const RowMap &rows, const 
 	}
 }
 
+// Calibration records (RowMap::measure): kMeasureStride words per tile row, see k_render_fast's last lines.
+__global__ __launch_bounds__(256) void k_measure_init(unsigned long long *rec, int n_words) {
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (i < n_words) rec[i] = 0ull;
+}
+// -> host_dst[2 t] = start of tile row t, host_dst[2 t + 1] = its longest wave
+__global__ __launch_bounds__(256) void k_measure_readback(const unsigned long long *__restrict__ rec, unsigned long long *__restrict__ host_dst, int tile_rows) {
+	const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (t >= tile_rows) return;
+	const unsigned long long *r = rec + (size_t)t * kMeasureStride;
+	unsigned long long m = 0;
+	for (int k = 1; k < kMeasureStride; ++k) m = r[k] > m ? r[k] : m;
+	host_dst[2 * t] = r[0];
+	host_dst[2 * t + 1] = m;
+}
+hipError_t launch_measure_init(unsigned long long *d_rec, int tile_rows, hipStream_t stream) {
+	const int n = tile_rows * kMeasureStride;
+	hipLaunchKernelGGL(k_measure_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_rec, n);
+	return hipGetLastError();
+}
+hipError_t launch_measure_readback(const unsigned long long *d_rec, unsigned long long *h_pinned_dev, int tile_rows, hipStream_t stream) {
+	hipLaunchKernelGGL(k_measure_readback, dim3((unsigned)((tile_rows + 255) / 256)), dim3(256), 0, stream, d_rec, h_pinned_dev, tile_rows);
+	return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_thr_to_float(const double *__restrict__ thr, float *__restrict__ dst, int64_t n) {
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)thr[i];
@@ -595,6 +672,45 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
 	const dim3 grid((unsigned)tiles_x, (unsigned)(tiles_y < 32768 ? tiles_y : 32768), (unsigned)((tiles_y + 32767) / 32768));
 	StatsOut st{d_counters, d_steps, d_entry};
+#ifdef HMRM_TIMELINE
+	{
+		static TimelineRec *host = nullptr;
+		static size_t cap = 0, used = 0;
+		static int gx = 0, gy = 0, rot = 0, ty = 0;
+		const size_t waves = (size_t)grid.x * grid.y * grid.z * (kBlockThreads / 64);
+		if (!stats) {
+			if (waves > cap) {
+				(void)hipDeviceSynchronize();
+				if (host) (void)hipHostFree(host);
+				(void)hipHostMalloc((void **)&host, waves * sizeof(TimelineRec), hipHostMallocMapped);
+				cap = waves;
+				TimelineRec *dev = nullptr;
+				(void)hipHostGetDevicePointer((void **)&dev, host, 0);
+				(void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &dev, sizeof dev);
+				static bool registered = false;
+				if (!registered) {
+					registered = true;
+					atexit([] {
+						const char *path = getenv("HMRM_TIMELINE_FILE");
+						if (!path || !host) return;
+						(void)hipDeviceSynchronize();
+						if (FILE *fp = fopen(path, "wb")) {
+							const int hdr[6] = {gx, gy, kBlockThreads / 64, (int)used, rot, ty};
+							fwrite(hdr, sizeof hdr, 1, fp);
+							fwrite(host, sizeof(TimelineRec), used, fp);
+							fclose(fp);
+						}
+					});
+				}
+			}
+			used = waves;
+			gx = (int)grid.x;
+			gy = (int)(grid.y * grid.z);
+			rot = rows.seg_delta[0];
+			ty = tiles_y;
+		}
+	}
+#endif
 	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 	return hipGetLastError();
