@@ -1474,6 +1474,32 @@ int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam, int32_t px, 
 	return HMRM_OK;
 }
 
+// Host-only test hook for the launch-order calibration: the plan api.cpp derives from the records of a measured launch
+// (tile_rows x {start of the row's first workgroup, longest wave of the row}, 10 ns ticks, measured under the plain
+// rotation by `rot`), and the grid-row -> tile-row map the kernel would apply for it.
+int hmrm_debug_plan_order(const uint64_t *records, int32_t tile_rows, int32_t rot, int32_t pieces_begin[3],
+                          int32_t pieces_count[3], int32_t *tile_row_of_grid_row) {
+	if (!records || !pieces_begin || !pieces_count || tile_rows <= 0 || rot < 0 || rot >= tile_rows) return fail(HMRM_E_ARG, "bad argument");
+	int b[3] = {0, 0, 0}, c[3] = {0, 0, 0};
+	const int n = plan_order_from_measurement((const unsigned long long *)records, tile_rows, rot, b, c);
+	for (int k = 0; k < 3; ++k) {
+		pieces_begin[k] = k < n ? b[k] : 0;
+		pieces_count[k] = k < n ? c[k] : 0;
+	}
+	if (tile_row_of_grid_row) {
+		hmrm::RowMap r{};
+		set_tile_order(&r, tile_rows, rot, n, b, c);
+		for (int gy = 0; gy < tile_rows; ++gy) { // device_common.hpp pixel_of_lane, restated
+			int delta = r.seg_delta[0];
+			for (int k = 1; k < hmrm::kOrderSegs; ++k) delta = (unsigned)gy >= (unsigned)r.seg_first[k - 1] ? r.seg_delta[k] : delta;
+			unsigned ty = (unsigned)gy + (unsigned)delta;
+			if (ty >= (unsigned)tile_rows) ty -= (unsigned)tile_rows;
+			tile_row_of_grid_row[gy] = (int32_t)ty;
+		}
+	}
+	return n;
+}
+
 // v_rcp_f64 accuracy on this device (render.hip k_rcp_error): the premise of slab_classify's margins.
 int hmrm_debug_rcp_error(int32_t mode, uint64_t count, uint64_t seed, int32_t exp_lo, int32_t exp_hi,
                          double *max_rel_err, uint64_t *hist64) {

@@ -109,6 +109,7 @@ def _load():
         "hmrm_render_stats": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(Stats), vp, vp]),
         "hmrm_debug_ray": (C.c_int, [vp, C.POINTER(Camera), i32, i32, dp, dp, dp]),
         "hmrm_debug_frame": (C.c_int, [C.POINTER(Camera), C.POINTER(SceneParams), i32, i32, vp, vp]),
+        "hmrm_debug_plan_order": (C.c_int, [vp, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
         "hmrm_debug_rcp_error": (C.c_int, [i32, C.c_uint64, C.c_uint64, i32, i32, dp, C.POINTER(C.c_uint64)]),
         "hmrm_last_kernel_ms": (C.c_double, []),
         "hmrm_bench_kernel_ms": (C.c_double, [vp, C.POINTER(Camera), i32]),
@@ -343,6 +344,18 @@ def debug_frame(cam: Camera, params: SceneParams, map_w: int, map_h: int):
         rec.update(col_cos_ha=tables[0:W], col_sin_ha=tables[W:2 * W],
                    row_sin_va=tables[2 * W:2 * W + H], row_cos_va=tables[2 * W + H:])
     return rec
+
+
+def plan_order(records: np.ndarray, rot: int):
+    """The launch-order plan for measured records ((tile_rows, 2) uint64: start, longest wave) -> (pieces, permutation)."""
+    rec = np.ascontiguousarray(records, dtype=np.uint64)
+    n_rows = rec.shape[0]
+    b, c = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    perm = np.empty(n_rows, dtype=np.int32)
+    n = lib.hmrm_debug_plan_order(_ptr(rec), n_rows, rot, b, c, _ptr(perm))
+    if n < 0:
+        raise HmrmError(n, last_error())
+    return [(b[k], c[k]) for k in range(n)], perm
 
 
 def rcp_error(mode: int, count: int, seed: int = 0, exp_lo: int = 0, exp_hi: int = 0):

@@ -217,6 +217,16 @@ int hmrm_debug_ray(const hmrm_scene *scene, const hmrm_camera *cam,
 int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params,
                      int32_t map_w, int32_t map_h, double *out25, double *tables);
 
+/* Host-only test hook (no GPU needed, no reference counterpart: the reference's OpenMP loop has no launch order).
+ * The library hands a frame's 16-row tile rows to the GPU in an order calibrated from one measured launch per
+ * cached camera: records[2 t] = start of tile row t's first workgroup, records[2 t + 1] = duration of its longest
+ * wave (10 ns ticks), measured under the plain rotation that starts at tile row `rot`.  Returns the number of
+ * contiguous pieces (0..3; 0 = the rotation stays) the plan starts first, in order, in pieces_begin / pieces_count,
+ * and, when tile_row_of_grid_row is not NULL (tile_rows entries), the resulting permutation: which tile row the
+ * grid's row j renders.  Scheduling only -- no order changes a pixel.  Negative = HMRM_E_ARG. */
+int hmrm_debug_plan_order(const uint64_t *records, int32_t tile_rows, int32_t rot, int32_t pieces_begin[3],
+                          int32_t pieces_count[3], int32_t *tile_row_of_grid_row);
+
 /* Accuracy of the hardware reciprocal v_rcp_f64 on the current device (test hook; no reference counterpart:
  * the reference divides, AABB.cpp:62-63, and the kernel's one-division shortcut through distance() must prove
  * from approximate quotients which exact quotient is the result).  mode 0: the leading 32 mantissa bits

@@ -1,0 +1,96 @@
+"""Host logic of the launch-order calibration (csrc/api.cpp plan_order_from_measurement / set_tile_order; CPU only).
+The plan is scheduling -- it can never change a pixel -- but it must always be a PERMUTATION of the tile rows, and on
+a measured profile like BASELINE config C3's (tools/timeline.py) it must move the bottom of the hot range in front of
+its middle."""
+import numpy as np
+import pytest
+
+
+def records(starts_us, longest_us):
+    rec = np.zeros((len(starts_us), 2), dtype=np.uint64)
+    rec[:, 0] = (np.asarray(starts_us) * 100).astype(np.uint64) + 123456789  # (an arbitrary clock origin)
+    rec[:, 1] = (np.asarray(longest_us) * 100).astype(np.uint64)
+    return rec
+
+
+def c3_like_profile(tile_rows=135, rot=43, end=103):
+    """Starts under the rotation and longest waves per tile row, shaped like the measured C3 launch: horizon rows with
+    very long waves first, a long middle of 40 us waves, a bottom band of 60 us waves, sky rows of 1 us."""
+    q = np.full(tile_rows, 1.0)
+    for t in range(rot, end):
+        i = t - rot
+        q[t] = 120.0 if i < 7 else (75.0 if i < 14 else (40.0 if t < end - 16 else 60.0))
+    start = np.zeros(tile_rows)
+    clock = 0.0
+    for i in range(tile_rows):
+        t = (rot + i) % tile_rows
+        start[t] = clock
+        clock += 1.4 if rot <= t < end else 0.25   # marching rows take longer to hand out
+    return records(start, q), q, start
+
+
+def model_makespan(perm, q, dispatch):
+    """max over rows of (start under the order + longest wave), the plan's own model."""
+    clock, worst = 0.0, 0.0
+    for t in perm:
+        worst = max(worst, clock + q[t])
+        clock += dispatch[t]
+    return worst
+
+
+def test_c3_like_profile_moves_the_bottom_band_forward(hmrm):
+    rec, q, start = c3_like_profile()
+    pieces, perm = hmrm.plan_order(rec, 43)
+    assert sorted(perm.tolist()) == list(range(135))            # a permutation of the tile rows
+    assert len(pieces) >= 2 and perm[0] == 43                   # the horizon rows still start first
+    pos = {int(t): i for i, t in enumerate(perm)}
+    assert pos[95] < pos[70]                                    # bottom band (60 us waves) before the middle (40 us)
+    dispatch = np.where((np.arange(135) >= 43) & (np.arange(135) < 103), 1.4, 0.25)
+    rotation = [(43 + i) % 135 for i in range(135)]
+    assert model_makespan(perm, q, dispatch) < 0.97 * model_makespan(rotation, q, dispatch)
+    # the pieces are disjoint, contiguous together, and inside the frame
+    rows = [t for b, c in pieces for t in range(b, b + c)]
+    assert len(set(rows)) == len(rows) and min(rows) == 43 and max(rows) - min(rows) + 1 == len(rows)
+
+
+def test_flat_and_monotone_profiles_keep_the_rotation(hmrm):
+    n, rot = 64, 10
+    start = np.array([((t - rot) % n) * 1.0 for t in range(n)])
+    for q in (np.full(n, 30.0), np.array([max(1.0, 80.0 - 1.2 * ((t - rot) % n)) for t in range(n)])):
+        pieces, perm = hmrm.plan_order(records(start, q), rot)
+        assert pieces == [] and perm.tolist() == [(rot + i) % n for i in range(n)]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_profiles_always_give_a_permutation(hmrm, seed):
+    rng = np.random.RandomState(seed)
+    n = int(rng.randint(12, 300))
+    rot = int(rng.randint(0, n))
+    q = rng.uniform(0.5, 100.0, size=n) * (rng.uniform(size=n) < rng.uniform(0.2, 1.0))
+    q = np.maximum(q, 0.3)
+    d = rng.uniform(0.1, 2.0, size=n)
+    start = np.zeros(n)
+    clock = 0.0
+    for i in range(n):
+        t = (rot + i) % n
+        start[t] = clock + (rng.uniform(-0.3, 0.3) if seed % 3 == 0 else 0.0)  # (noisy starts too)
+        clock += d[t]
+    start -= start.min()
+    pieces, perm = hmrm.plan_order(records(start, q), rot)
+    assert sorted(perm.tolist()) == list(range(n)), (pieces, rot, n)
+    assert len(pieces) <= 3
+    if pieces:
+        rows = [t for b, c in pieces for t in range(b, b + c)]
+        assert len(set(rows)) == len(rows) and all(0 <= t < n for t in rows)
+        assert max(rows) - min(rows) + 1 == len(rows) and min(rows) >= rot   # one contiguous range, not wrapping
+
+
+def test_bad_arguments_and_missing_records(hmrm):
+    rec, _, _ = c3_like_profile()
+    with pytest.raises(hmrm.HmrmError):
+        hmrm.plan_order(rec, 135)
+    rec[50, 0] = 0                       # a tile row that never reported: no plan, the rotation stays
+    pieces, perm = hmrm.plan_order(rec, 43)
+    assert pieces == [] and perm.tolist() == [(43 + i) % 135 for i in range(135)]
+    pieces, perm = hmrm.plan_order(rec[:8], 3)   # too few rows to bother
+    assert pieces == [] and sorted(perm.tolist()) == list(range(8))

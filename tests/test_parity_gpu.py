@@ -1110,6 +1110,39 @@ def test_launch_order_never_changes_a_pixel(gpu, oracle):
             assert np.array_equal(strip, ofb[48:131]), (proj, order)
 
 
+def test_calibrated_and_pieced_launch_orders_never_change_a_pixel(gpu, oracle, capfd):
+    """The launch order beyond the rotation (api.cpp: up to three tile-row pieces started first, the rest wrapping
+    around; calibrated per cached camera from a measured launch, then verified by a second measured launch) is
+    scheduling only.  A camera rendered again and again walks through every calibration state -- plain, measured,
+    candidate measured, settled -- and every frame, on the scene's stream and on a caller's, equals the oracle's;
+    so do frames under explicit pieces (HMRM_TILE_SEGMENTS, a tool knob), valid ones in any order and invalid ones
+    (overlapping, not contiguous, out of range), which fall back to the rotation."""
+    import torch
+    rgb, cmap = scenes.small_maps(200, 180, 4243)
+    params = gpu.SceneParams.make(0.0, 14.0, grid_width=1.0)
+    heights = oracle.update_heightmap(rgb, params)
+    st = torch.cuda.Stream()
+    with env(HMRM_ORDER_VERBOSE=1):
+        scene = gpu.Scene(rgb, cmap, params)
+        for proj, vang in ((2, 100.0), (1, 95.0), (3, 125.0)):
+            cam = gpu.Camera.make(width=251, height=420, projection=proj, hfov=gpu.degrees_to_rads(160 if proj == 2 else 85),
+                                  hang=gpu.degrees_to_rads(-45), vang=gpu.degrees_to_rads(vang), pos=(-25.0, 25.0, 34.0),
+                                  ortho_width=0.6, step_dist=0.25, bg=(4, 5, 6))
+            ofb, *_ = oracle.render(oracle.make_cfg(cam, params, 200, 180), heights, cmap)
+            buf = torch.zeros((cam.height, cam.width, 4), dtype=torch.uint8, device="cuda")
+            for rep in range(7):
+                assert np.array_equal(scene.render(cam), ofb), (proj, rep)
+                scene.render_rows_device(cam, buf.data_ptr(), cam.width * 4, 0, cam.height, stream=st.cuda_stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(buf.cpu().numpy(), ofb), (proj, rep)
+            for segs in ("9:5,20:6,14:6", "20:6,9:5,14:6", "0:27", "3:4", "26:1,25:1,24:1", "9:5,12:6", "9:5,20:6", "5:40", "9:5,14:6,20:6"):
+                with env(HMRM_TILE_SEGMENTS=segs):
+                    assert np.array_equal(scene.render(cam), ofb), (proj, segs)
+        scene.close()
+    err = capfd.readouterr().err
+    assert err.count("hmrm order: rotation") >= 3, err   # every camera above was measured at least once
+
+
 def test_very_tall_frame_uses_the_third_grid_dimension(gpu, oracle):
     """More than 32768 tile rows (16 pixels each): the launch folds the rows into grid y and z."""
     rgb, cmap = scenes.small_maps(40, 33, 77)
