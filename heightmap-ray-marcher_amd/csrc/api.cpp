@@ -116,13 +116,18 @@ struct FrameSlot {
 	double *d_tables = nullptr;  // spherical sin/cos tables: this slot's piece of the context's arenas
 	double *h_tables = nullptr;  // pinned staging, likewise
 	hipEvent_t uploaded = nullptr; // after the H2D copy out of h_tables: the host may rewrite them then
-	// Launch order calibrated by measurement (calibrate_order below).  order_state: 0 rotation, nothing measured;
-	// 1 a measured launch under the rotation is in flight; 2 a measured launch under the candidate order is in
-	// flight; 3 settled (order_n pieces, 0 = the rotation stays).
-	int order_state = 0;
+	// Launch order calibrated by measurement (plan_order_from_measurement below): a short list of trial orders, each
+	// timed by one measured full-frame launch -- [0] the rotation, then the model's plan and a generic head / tail /
+	// middle split of the measured hot range -- after which the one with the shortest measured makespan stays.
+	struct OrderTrial {
+		int n = 0, b[3] = {0, 0, 0}, c[3] = {0, 0, 0}; // pieces (n = 0: the plain rotation)
+		double makespan = 0.0;                         // measured, ticks; 0 = not yet
+	};
+	OrderTrial trials[3];
+	int n_trials = 1;              // known so far (the candidates are made from the rotation's records)
+	int trial_in_flight = -1;      // the trial whose measured launch has not been read yet
+	int order_best = -1;           // settled: index into trials (-1: still calibrating, the rotation is used)
 	uint32_t uses = 0;             // full-frame launches of this record
-	int order_n = 0, order_b[3] = {0, 0, 0}, order_c[3] = {0, 0, 0};
-	double base_makespan = 0.0;    // measured under the rotation (ticks)
 	int meas_rows = 0;             // tile rows of the measured launch in flight
 	hipEvent_t measured = nullptr; // after the read-back of a measured launch
 };
@@ -310,6 +315,23 @@ double measured_makespan(const unsigned long long *rec, int tiles_y) {
 	return m;
 }
 
+// A generic candidate that needs no model: the measured hot range [rot, last row whose longest wave is >= 5 % of the
+// frame's longest) cut into head, middle and tail by fractions; order head, tail, middle.  -> pieces (0: none).
+int split_hot_range(const unsigned long long *rec, int tiles_y, int rot, double head_frac, double tail_frac, int *pb, int *pc) {
+	if (tiles_y < 12 || rot < 0 || rot >= tiles_y) return 0;
+	unsigned long long qmax = 0;
+	for (int t = 0; t < tiles_y; ++t) qmax = std::max(qmax, rec[2 * t + 1]);
+	int n = 0;
+	for (int t = rot; t < tiles_y; ++t)
+		if ((double)rec[2 * t + 1] >= 0.05 * (double)qmax) n = t - rot + 1;
+	const int head = (int)(n * head_frac), tail = (int)(n * tail_frac);
+	if (n < 12 || head < 1 || tail < 1 || head + tail >= n) return 0;
+	pb[0] = rot;            pc[0] = head;
+	pb[1] = rot + n - tail; pc[1] = tail;
+	pb[2] = rot + head;     pc[2] = n - head - tail;
+	return 3;
+}
+
 // -> number of pieces (0: keep the rotation); records measured under the rotation by `rot`.
 int plan_order_from_measurement(const unsigned long long *rec, int tiles_y, int rot, int *pb, int *pc) {
 	if (tiles_y < 12 || rot < 0 || rot >= tiles_y) return 0;
@@ -468,10 +490,12 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 				if (!sl.valid) break;
 			}
 		slot->valid = false;
-		if (slot->order_state == 1 || slot->order_state == 2) HIP_TRY(hipEventSynchronize(slot->measured)); // (its records are about to be reused)
-		slot->order_state = 0;
+		if (slot->trial_in_flight >= 0) HIP_TRY(hipEventSynchronize(slot->measured)); // (its records are about to be reused)
+		slot->trial_in_flight = -1;
+		slot->order_best = -1;
+		slot->n_trials = 1;
+		for (FrameSlot::OrderTrial &t : slot->trials) t = FrameSlot::OrderTrial();
 		slot->uses = 0;
-		slot->order_n = 0;
 		hmrm::HostCamera hc;
 		to_host_camera(cam, &hc);
 		double *cc = nullptr, *cs = nullptr, *rs = nullptr, *rc = nullptr;
@@ -591,7 +615,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
                  uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats) {
 	hmrm::RowMap rows_in_order = rows;
 	bool measure_now = false;
-	int tiles_y = 0;
+	int tiles_y = 0, trial_now = -1;
 	{
 		int tile_w = 1, tile_h = 1;
 		hmrm::render_tile_shape(&tile_w, &tile_h);
@@ -608,37 +632,47 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 			++slot->uses;
 			const size_t idx = (size_t)(slot - c->slots);
 			unsigned long long *h_rec = c->h_meas ? c->h_meas + idx * 2 * kMaxMeasRows : nullptr;
-			if ((slot->order_state == 1 || slot->order_state == 2) && slot->meas_rows == tiles_y &&
-			    hipEventQuery(slot->measured) == hipSuccess) {
-				if (slot->order_state == 1) {
-					slot->base_makespan = measured_makespan(h_rec, tiles_y);
-					slot->order_n = plan_order_from_measurement(h_rec, tiles_y, rot, slot->order_b, slot->order_c);
-					slot->order_state = slot->order_n > 0 ? 10 : 3; // 10: candidate ready, to be measured by this launch
-					if (s->knobs.order_verbose) {
-						fprintf(stderr, "hmrm order: rotation %d of %d tile rows measured, makespan %.1f us; candidate:", rot, tiles_y, slot->base_makespan / 100.0);
-						for (int k = 0; k < slot->order_n; ++k) fprintf(stderr, " [%d,%d)", slot->order_b[k], slot->order_b[k] + slot->order_c[k]);
-						fprintf(stderr, "%s\n", slot->order_n ? "" : " none (the model predicts < 3 % gain)");
-					}
-				} else {
-					const double got = measured_makespan(h_rec, tiles_y);
-					if (!(got < 0.99 * slot->base_makespan)) slot->order_n = 0; // the rotation stays
-					slot->order_state = 3;
-					if (s->knobs.order_verbose)
-						fprintf(stderr, "hmrm order: candidate measured, makespan %.1f us against %.1f us: %s\n", got / 100.0,
-						        slot->base_makespan / 100.0, slot->order_n ? "kept" : "dropped");
+			if (slot->trial_in_flight >= 0 && slot->meas_rows == tiles_y && hipEventQuery(slot->measured) == hipSuccess) {
+				FrameSlot::OrderTrial &t = slot->trials[slot->trial_in_flight];
+				t.makespan = std::max(1.0, measured_makespan(h_rec, tiles_y));
+				if (slot->trial_in_flight == 0) { // the rotation's records: make the candidates
+					FrameSlot::OrderTrial &plan = slot->trials[slot->n_trials];
+					plan.n = plan_order_from_measurement(h_rec, tiles_y, rot, plan.b, plan.c);
+					if (plan.n > 0) ++slot->n_trials;
+					FrameSlot::OrderTrial &split = slot->trials[slot->n_trials];
+					split.n = split_hot_range(h_rec, tiles_y, rot, 0.45, 0.25, split.b, split.c);
+					const bool same = split.n == plan.n && slot->n_trials > 1 && memcmp(split.b, plan.b, sizeof split.b) == 0 &&
+					                  memcmp(split.c, plan.c, sizeof split.c) == 0;
+					if (split.n > 0 && !same) ++slot->n_trials;
+				}
+				if (s->knobs.order_verbose) {
+					fprintf(stderr, "hmrm order: trial %d of %d tile rows measured, makespan %.1f us:", slot->trial_in_flight, tiles_y, t.makespan / 100.0);
+					for (int k = 0; k < t.n; ++k) fprintf(stderr, " [%d,%d)", t.b[k], t.b[k] + t.c[k]);
+					fprintf(stderr, "%s\n", t.n ? "" : " rotation");
+				}
+				slot->trial_in_flight = -1;
+				int next = -1;
+				for (int k = 0; k < slot->n_trials; ++k)
+					if (slot->trials[k].makespan == 0.0) { next = k; break; }
+				if (next < 0) { // all timed: the shortest stays; another order must beat the rotation by 1 %
+					int best = 0;
+					for (int k = 1; k < slot->n_trials; ++k)
+						if (slot->trials[k].makespan < 0.99 * slot->trials[0].makespan && slot->trials[k].makespan < slot->trials[best].makespan) best = k;
+					slot->order_best = best;
+					if (s->knobs.order_verbose) fprintf(stderr, "hmrm order: settled on trial %d\n", best);
 				}
 			}
 			// (one measured launch per context at a time: they share the device records)
-			if (c->meas_owner && (c->meas_owner->order_state == 3 || c->meas_owner->order_state == 0 ||
-			                      hipEventQuery(c->meas_owner->measured) == hipSuccess))
+			if (c->meas_owner && (c->meas_owner->trial_in_flight < 0 || hipEventQuery(c->meas_owner->measured) == hipSuccess))
 				c->meas_owner = nullptr;
-			const bool free_records = c->meas_owner == nullptr;
-			if (slot->order_state == 0 && slot->uses >= 2 && free_records) measure_now = true; // -> 1
-			if (slot->order_state == 10 && free_records) measure_now = true;                    // -> 2
-			if (slot->order_state == 10 || slot->order_state == 2 || slot->order_state == 3) {
-				nb = slot->order_n;
-				for (int k = 0; k < nb; ++k) { b[k] = slot->order_b[k]; c3[k] = slot->order_c[k]; }
+			int use = slot->order_best >= 0 ? slot->order_best : 0;
+			if (slot->order_best < 0 && slot->trial_in_flight < 0 && slot->uses >= 2 && c->meas_owner == nullptr) {
+				for (int k = 0; k < slot->n_trials; ++k)
+					if (slot->trials[k].makespan == 0.0) { use = k; measure_now = true; break; }
+				if (measure_now) trial_now = use;
 			}
+			nb = slot->trials[use].n;
+			for (int k = 0; k < nb; ++k) { b[k] = slot->trials[use].b[k]; c3[k] = slot->trials[use].c[k]; }
 		}
 		set_tile_order(&rows_in_order, tiles_y, rot, nb, b, c3);
 	}
@@ -671,7 +705,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 		HIP_TRY(hmrm::launch_measure_readback(rows_in_order.measure, c->h_meas_dev + idx * 2 * kMaxMeasRows, tiles_y, c->stream));
 		HIP_TRY(hipEventRecord(slot->measured, c->stream));
 		slot->meas_rows = tiles_y;
-		slot->order_state = slot->order_state == 10 ? 2 : 1;
+		slot->trial_in_flight = trial_now;
 	}
 	// (only streams other than the scene's own can be recycled, ctx_for)
 	if (c->stream != s->stream) HIP_TRY(hipEventRecord(c->last_launch, c->stream));

@@ -1130,7 +1130,7 @@ def test_calibrated_and_pieced_launch_orders_never_change_a_pixel(gpu, oracle, c
                                   ortho_width=0.6, step_dist=0.25, bg=(4, 5, 6))
             ofb, *_ = oracle.render(oracle.make_cfg(cam, params, 200, 180), heights, cmap)
             buf = torch.zeros((cam.height, cam.width, 4), dtype=torch.uint8, device="cuda")
-            for rep in range(7):
+            for rep in range(9):
                 assert np.array_equal(scene.render(cam), ofb), (proj, rep)
                 scene.render_rows_device(cam, buf.data_ptr(), cam.width * 4, 0, cam.height, stream=st.cuda_stream)
                 torch.cuda.synchronize()
@@ -1140,7 +1140,7 @@ def test_calibrated_and_pieced_launch_orders_never_change_a_pixel(gpu, oracle, c
                     assert np.array_equal(scene.render(cam), ofb), (proj, segs)
         scene.close()
     err = capfd.readouterr().err
-    assert err.count("hmrm order: rotation") >= 3, err   # every camera above was measured at least once
+    assert err.count("hmrm order: trial 0 of") >= 3 and err.count("hmrm order: settled") >= 3, err   # every camera was calibrated
 
 
 def test_very_tall_frame_uses_the_third_grid_dimension(gpu, oracle):
