@@ -23,13 +23,20 @@ __device__ __forceinline__ double f64_from_hi(uint32_t hi) { return __longlong_a
 //   GWM 2: any grid_width      -> q' = v * fl(1/gw), which differs from the correctly rounded
 //          v/gw by < 2^-50 relative.  Unless q' lies within 2^-20 of an integer both truncate to
 //          the same cell (for |q'| >= 2^28 both are far outside any map, whatever they truncate
-//          to); `near` collects that rare case and the caller then divides for real.
+//          to); `near` collects that rare case and the caller then divides for real.  What is returned is
+//          q' + 2^-20 (one fused multiply-add: this is an approximation anyway), so that the test is one
+//          v_fract and one compare -- near  <=>  fract(q' + 2^-20) < 2^-19  <=>  q' in [k - 2^-20, k + 2^-20) --
+//          and off that neighbourhood trunc(q' + 2^-20) == trunc(q') on either side of zero.  Callers only
+//          truncate the value (or replace it by the true quotient).
 template <int GWM>
 __device__ __forceinline__ double cell_coord_fast(double v, const DevFrame &f, bool &near) {
 	if (GWM == 0) return v;
-	const double q = v * f.inv_grid_width;
-	if (GWM == 2) near = near || !(__builtin_fabs(__builtin_amdgcn_fract(q) - 0.5) < 0.5 - 0x1p-20);
-	return q;
+	if (GWM == 2) {
+		const double q = __builtin_fma(v, f.inv_grid_width, 0x1p-20);
+		near = near || !(__builtin_amdgcn_fract(q) >= 0x1p-19); // (NaN: near)
+		return q;
+	}
+	return v * f.inv_grid_width;
 }
 
 // (int)q exactly as the reference's x86 build evaluates it for the range test of hmap.cpp:1001-
