@@ -577,32 +577,23 @@ std::vector<uint8_t> convert_channels8(const std::vector<uint8_t> &src, int from
 	return convert_channels<uint8_t>(src, from, to, npix, 255);
 }
 
-// Format detection by signature: PNG, BMP, JPEG, PNM; TGA last (it has no signature, only a header
-// that must be plausible).  GIF, PSD, PIC and Radiance HDR -- which the reference's stb_image also
-// reads (README.md:75) -- are not decoded natively: they are named in the error so that a user can
-// convert the map, and INTEGRATION.md shows how an embedder hands over pixels decoded elsewhere.
+// Format detection in the order the reference's loader tries them (stb_image v2.27 stbi__load_main): the formats
+// with a real signature first -- PNG, BMP, GIF, PSD, PIC -- then JPEG, PNM and Radiance HDR, and TGA last (it has no
+// signature, only a header that must be plausible).  All nine formats the reference's README lists for maps.
 bool decode_image(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err) {
 	if (req_comp < 0 || req_comp > 4) { *err = "bad req_comp"; return false; }
 	static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
 	if (len >= 8 && memcmp(bytes, sig, 8) == 0) return decode_png(bytes, len, req_comp, out, err);
 	if (looks_like_bmp(bytes, len)) return decode_bmp(bytes, len, req_comp, out, err);
-	if (len >= 6 && (memcmp(bytes, "GIF87a", 6) == 0 || memcmp(bytes, "GIF89a", 6) == 0)) {
-		*err = "GIF maps are not decoded natively (convert to PNG, JPEG, BMP, TGA or PNM)";
-		return false;
-	}
-	if (len >= 4 && memcmp(bytes, "8BPS", 4) == 0) {
-		*err = "PSD maps are not decoded natively (convert to PNG, JPEG, BMP, TGA or PNM)";
-		return false;
-	}
-	if (len >= 10 && (memcmp(bytes, "#?RADIANCE", 10) == 0 || memcmp(bytes, "#?RGBE", 6) == 0)) {
-		*err = "Radiance HDR maps are not decoded natively (convert to PNG, JPEG, BMP, TGA or PNM)";
-		return false;
-	}
+	if (looks_like_gif(bytes, len)) return decode_gif(bytes, len, req_comp, out, err);
+	if (looks_like_psd(bytes, len)) return decode_psd(bytes, len, req_comp, out, err);
+	if (looks_like_pic(bytes, len)) return decode_pic(bytes, len, req_comp, out, err);
 	if (len >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8) return decode_jpeg(bytes, len, req_comp, out, err);
 	if (len >= 2 && bytes[0] == 'P' && (bytes[1] == '5' || bytes[1] == '6'))
 		return decode_pnm(bytes, len, req_comp, out, err);
+	if (looks_like_hdr(bytes, len)) return decode_hdr(bytes, len, req_comp, out, err);
 	if (looks_like_tga(bytes, len)) return decode_tga(bytes, len, req_comp, out, err);
-	*err = "unknown image type (supported: PNG, JPEG, BMP, TGA, binary PGM/PPM)";
+	*err = "unknown image type (supported: PNG, JPEG, BMP, GIF, PSD, PIC, HDR, TGA, binary PGM/PPM)";
 	return false;
 }
 

@@ -15,7 +15,7 @@ struct Image {
 	std::vector<uint8_t> px;  // row-major, top-left origin, 8 bits per channel
 };
 
-// Decode PNG, JPEG, BMP, TGA or binary PNM from memory into 8-bit channels, converted to
+// Decode PNG, JPEG, BMP, GIF, PSD, PIC, Radiance HDR, TGA or binary PNM from memory into 8-bit channels, converted to
 // req_comp (0 = keep) the way stb_image v2.27's stbi_load does.  On failure
 // returns false and sets err to a short reason.
 bool decode_image(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
@@ -27,6 +27,16 @@ bool looks_like_bmp(const uint8_t *bytes, size_t len);
 bool decode_bmp(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
 bool looks_like_tga(const uint8_t *bytes, size_t len);
 bool decode_tga(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
+// GIF (first image), Photoshop PSD (composite, RGB), Softimage PIC, Radiance HDR tone-mapped to 8 bits
+// (legacy_formats.cpp), same conventions.
+bool looks_like_gif(const uint8_t *bytes, size_t len);
+bool decode_gif(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
+bool looks_like_psd(const uint8_t *bytes, size_t len);
+bool decode_psd(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
+bool looks_like_pic(const uint8_t *bytes, size_t len);
+bool decode_pic(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
+bool looks_like_hdr(const uint8_t *bytes, size_t len);
+bool decode_hdr(const uint8_t *bytes, size_t len, int req_comp, Image *out, std::string *err);
 // stb's channel conversion table for 8-bit data (grey<->RGB, alpha add/drop, luma).
 std::vector<uint8_t> convert_channels8(const std::vector<uint8_t> &src, int from, int to, size_t npix);
 

@@ -8,7 +8,7 @@
   png_decode.npz  small PNG/PNM files (bytes) and, for req_comp 0..4, the pixels
                   the REFERENCE's own stb_image v2.27 decodes from them
                   (oracle/_ref/libstb_ref.so, built from /root/reference/vendor).
-  jpeg_decode.npz / bmp_tga_decode.npz  the same for JPEG, BMP and TGA files
+  jpeg_decode.npz / bmp_tga_decode.npz / legacy_decode.npz  the same for JPEG, BMP, TGA, GIF, PSD, PIC and HDR files
   png_encode.json sha256 + length of the files the REFERENCE's stb_image_write
                   v1.16 writes for seeded test images.
 
@@ -353,6 +353,300 @@ def make_jpeg_decode(ref):
 
 
 
+# ---------------------------------------------------- GIF / PSD / PIC / HDR ----
+def _gif_lzw(indices, min_bits, with_clear=True, early_end=None):
+    """GIF's variable-width LZW encoder (clear code first, dictionary reset at 4096), sub-block packed."""
+    clear, end = 1 << min_bits, (1 << min_bits) + 1
+    table = {bytes([i]): i for i in range(clear)}
+    nxt, width = end + 1, min_bits + 1
+    codes = [(clear, width)] if with_clear else []
+    cur = b""
+    for k, i in enumerate(indices):
+        if early_end is not None and k == early_end:
+            break
+        c = cur + bytes([i])
+        if c in table:
+            cur = c
+            continue
+        codes.append((table[cur], width))
+        if nxt < 4096:
+            table[c] = nxt
+            nxt += 1
+            if nxt - 1 == (1 << width) and width < 12:
+                width += 1
+        else:
+            codes.append((clear, width))
+            table = {bytes([j]): j for j in range(clear)}
+            nxt, width = end + 1, min_bits + 1
+        cur = bytes([i])
+    if cur:
+        codes.append((table[cur], width))
+    codes.append((end, width))
+    acc = nbits = 0
+    raw = bytearray()
+    for code, w in codes:
+        acc |= code << nbits
+        nbits += w
+        while nbits >= 8:
+            raw.append(acc & 255)
+            acc >>= 8
+            nbits -= 8
+    if nbits:
+        raw.append(acc & 255)
+    out = bytearray([min_bits])
+    for i in range(0, len(raw), 255):
+        chunk = raw[i:i + 255]
+        out.append(len(chunk))
+        out += chunk
+    out.append(0)
+    return bytes(out)
+
+
+def _gif(w, h, frames, version=b"89a", global_pal=None, bg=0, trailer=True):
+    """frames: list of dicts(rect=(x,y,w,h), indices, interlace, local_pal, transparent, min_bits, pre=bytes)."""
+    flags = 0
+    body = b""
+    if global_pal is not None:
+        bits = max(1, (len(global_pal) // 3 - 1).bit_length())
+        flags = 0x80 | (bits - 1) | ((bits - 1) << 4)
+        global_pal = global_pal + b"\0" * (3 * (1 << bits) - len(global_pal))
+    out = b"GIF" + version + struct.pack("<HHBBB", w, h, flags, bg, 0) + (global_pal or b"")
+    for f in frames:
+        out += f.get("pre", b"")
+        if f.get("transparent") is not None or f.get("gce"):
+            t = f.get("transparent")
+            out += b"\x21\xF9\x04" + bytes([(f.get("dispose", 0) << 2) | (1 if t is not None else 0)]) + struct.pack("<H", 7) + bytes([t or 0]) + b"\0"
+        x, y, fw, fh = f["rect"]
+        lflags = 0x40 if f.get("interlace") else 0
+        lp = f.get("local_pal")
+        if lp is not None:
+            bits = max(1, (len(lp) // 3 - 1).bit_length())
+            lflags |= 0x80 | (bits - 1)
+            lp = lp + b"\0" * (3 * (1 << bits) - len(lp))
+        out += b"\x2C" + struct.pack("<HHHHB", x, y, fw, fh, lflags) + (lp or b"")
+        idx = list(f["indices"])
+        if f.get("interlace"):
+            rows = [idx[r * fw:(r + 1) * fw] for r in range(fh)]
+            order = [r for s0, st in ((0, 8), (4, 8), (2, 4), (1, 2)) for r in range(s0, fh, st)]
+            idx = [v for r in order for v in rows[r]]
+        out += _gif_lzw(idx, f.get("min_bits", 8), early_end=f.get("early_end"))
+    return out + (b"\x3B" if trailer else b"")
+
+
+def _packbits(row):
+    out, i = bytearray(), 0
+    while i < len(row):
+        j = i
+        while j + 1 < len(row) and row[j + 1] == row[i] and j - i < 127:
+            j += 1
+        if j > i:
+            out += bytes([257 - (j - i + 1), row[i]])
+            i = j + 1
+            continue
+        j = i
+        while j + 1 < len(row) and (j + 2 >= len(row) or row[j + 1] != row[j + 2]) and j - i < 127:
+            j += 1
+        out += bytes([j - i]) + bytes(row[i:j + 1])
+        i = j + 1
+    return bytes(out)
+
+
+def _psd(planes, depth=8, rle=False, mode=3, resources=b"", extra_noop=False):
+    """planes: list of HxW arrays (uint8 or uint16) in channel order R,G,B,A,..."""
+    h, w = planes[0].shape
+    hdr = b"8BPS" + struct.pack(">H6xHIIHH", 1, len(planes), h, w, depth, mode)
+    hdr += struct.pack(">I", 0) + struct.pack(">I", len(resources)) + resources + struct.pack(">I", 0)
+    if not rle:
+        data = b"".join((p.astype(">u2") if depth == 16 else p.astype(np.uint8)).tobytes() for p in planes)
+        return hdr + struct.pack(">H", 0) + data
+    rows = [_packbits(bytes(p[r].astype(np.uint8))) for p in planes for r in range(h)]
+    if extra_noop:
+        rows = [b"\x80" + r for r in rows]
+    return hdr + struct.pack(">H", 1) + b"".join(struct.pack(">H", len(r)) for r in rows) + b"".join(rows)
+
+
+def _pic(w, h, packets, rows_of):
+    """packets: list of (type, channel mask); rows_of(y, packet index) -> encoded bytes of that packet's row."""
+    hdr = b"\x53\x80\xF6\x34" + struct.pack(">f", 3.7) + b"fixture".ljust(80, b"\0") + b"PICT" + struct.pack(">HHfHH", w, h, 1.0, 3, 0)
+    for k, (t, mask) in enumerate(packets):
+        hdr += bytes([1 if k + 1 < len(packets) else 0, 8, t, mask])
+    return hdr + b"".join(rows_of(y, k) for y in range(h) for k in range(len(packets)))
+
+
+def _rgbe(rgb):
+    """float HxWx3 -> uint8 HxWx4 (Ward's RGBE)."""
+    m = rgb.max(axis=2)
+    out = np.zeros(rgb.shape[:2] + (4,), dtype=np.uint8)
+    mant, exp = np.frexp(m)
+    scale = np.where(m > 1e-32, mant * 256.0 / np.maximum(m, 1e-38), 0.0)
+    out[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    out[..., 3] = np.where(m > 1e-32, exp + 128, 0).astype(np.uint8)
+    return out
+
+
+def _hdr(rgbe, rle=True, magic=b"#?RADIANCE", extra=b"EXPOSURE=1.0\n", raw_run_mix=True):
+    h, w = rgbe.shape[:2]
+    out = magic + b"\n" + extra + b"FORMAT=32-bit_rle_rgbe\n\n" + b"-Y %d +X %d\n" % (h, w)
+    if not rle:
+        return out + rgbe.tobytes()
+    for y in range(h):
+        out += bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            row, i = rgbe[y, :, c], 0
+            while i < w:
+                j = i
+                while j + 1 < w and row[j + 1] == row[i] and j - i < 126:
+                    j += 1
+                if j - i >= 2 or not raw_run_mix:
+                    out += bytes([128 + (j - i + 1), row[i]])
+                    i = j + 1
+                else:
+                    j = i
+                    while j + 1 < w and j - i < 127 and not (j + 2 < w and row[j + 1] == row[j + 2]):
+                        j += 1
+                    out += bytes([j - i + 1]) + bytes(row[i:j + 1])
+                    i = j + 1
+    return out
+
+
+def legacy_fixture_files():
+    """GIF, PSD, PIC and Radiance HDR variants, all hand-assembled (the encoders above are this script's own)."""
+    rng = np.random.RandomState(4321)
+    files = {}
+    pal8 = bytes(rng.randint(0, 256, size=3 * 256).astype(np.uint8))
+    pal4 = bytes(rng.randint(0, 256, size=3 * 16).astype(np.uint8))
+    w, h = 23, 17
+    smooth = (np.add.outer(np.arange(h) * 7, np.arange(w) * 5) % 256).astype(np.uint8)
+    noisy = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+    files["gif87_global"] = _gif(w, h, [dict(rect=(0, 0, w, h), indices=noisy.ravel())], version=b"87a", global_pal=pal8)
+    files["gif89_transparent"] = _gif(w, h, [dict(rect=(0, 0, w, h), indices=smooth.ravel() % 16, transparent=5, min_bits=4)], global_pal=pal4)
+    files["gif_interlaced"] = _gif(w, h, [dict(rect=(0, 0, w, h), indices=noisy.ravel(), interlace=True)], global_pal=pal8)
+    files["gif_local_palette"] = _gif(w, h, [dict(rect=(0, 0, w, h), indices=noisy.ravel() % 16, local_pal=pal4, min_bits=4)])
+    files["gif_local_transparent"] = _gif(w, h, [dict(rect=(0, 0, w, h), indices=noisy.ravel() % 16, local_pal=pal4, min_bits=4, transparent=3)], global_pal=pal8)
+    files["gif_subrect_bg"] = _gif(w, h, [dict(rect=(4, 3, 11, 9), indices=noisy[:9, :11].ravel())], global_pal=pal8, bg=77)
+    files["gif_subrect_bg0"] = _gif(w, h, [dict(rect=(4, 3, 11, 9), indices=noisy[:9, :11].ravel())], global_pal=pal8, bg=0)
+    files["gif_subrect_transparent_bg"] = _gif(w, h, [dict(rect=(2, 1, 15, 12), indices=noisy[:12, :15].ravel() % 16, transparent=9, min_bits=4, interlace=True)],
+                                               global_pal=pal4, bg=9)
+    files["gif_two_frames"] = _gif(w, h, [dict(rect=(0, 0, w, h), indices=smooth.ravel()), dict(rect=(1, 1, 5, 5), indices=noisy[:5, :5].ravel(), gce=True, dispose=2)],
+                                   global_pal=pal8)
+    files["gif_extensions_first"] = _gif(w, h, [dict(rect=(0, 0, w, h), indices=noisy.ravel(), pre=b"\x21\xFE\x05hello\x00" + b"\x21\xFF\x0bNETSCAPE2.0\x03\x01\x00\x00\x00")],
+                                         global_pal=pal8)
+    big = rng.randint(0, 256, size=(70, 90)).astype(np.uint8)   # > 4096 dictionary entries: the table is reset mid-stream
+    files["gif_dictionary_reset"] = _gif(90, 70, [dict(rect=(0, 0, 90, 70), indices=big.ravel())], global_pal=pal8)
+    files["gif_2colour"] = _gif(9, 5, [dict(rect=(0, 0, 9, 5), indices=(noisy[:5, :9] & 1).ravel(), min_bits=2)], global_pal=pal8[:6])
+    files["gif_runs"] = _gif(64, 8, [dict(rect=(0, 0, 64, 8), indices=np.repeat(np.arange(8, dtype=np.uint8), 64))], global_pal=pal8)  # KwKwK codes
+    files["gif_short_data"] = _gif(w, h, [dict(rect=(0, 0, w, h), indices=noisy.ravel(), early_end=200)], global_pal=pal8, bg=3)
+    files["gif_truncated"] = files["gif87_global"][:1000]          # ends inside the raster data: decodes as far as it goes
+    files["gif_truncated_palette"] = files["gif87_global"][:400]   # ends inside the colour table: refused
+    files["gif_interlaced_tiny"] = _gif(5, 3, [dict(rect=(0, 0, 5, 3), indices=noisy[:3, :5].ravel(), interlace=True)], global_pal=pal8)
+
+    pw, ph = 13, 9
+    planes = [rng.randint(0, 256, size=(ph, pw)).astype(np.uint8) for _ in range(5)]
+    runs = [np.repeat(rng.randint(0, 256, size=(ph, 3)).astype(np.uint8), 5, axis=1)[:, :pw] for _ in range(4)]
+    files["psd_rgb_raw"] = _psd(planes[:3])
+    files["psd_rgba_raw"] = _psd(planes[:4])
+    files["psd_rgb_rle"] = _psd(runs[:3], rle=True)
+    files["psd_rgba_rle"] = _psd(runs[:4], rle=True, resources=b"8BIM" + bytes(12))
+    files["psd_rgba_rle_noop"] = _psd(planes[:4], rle=True, extra_noop=True)
+    files["psd_5_channels"] = _psd(planes[:5])
+    files["psd_1_channel"] = _psd(planes[:1])
+    files["psd_2_channels_rle"] = _psd(runs[:2], rle=True)
+    files["psd_16bit_raw"] = _psd([rng.randint(0, 65536, size=(ph, pw)).astype(np.uint16) for _ in range(4)], depth=16)
+    alpha_edge = planes[:3] + [np.tile(np.array([0, 1, 2, 127, 128, 200, 254, 255, 3, 77, 250, 9, 255], dtype=np.uint8), (ph, 1))]
+    files["psd_alpha_matte"] = _psd(alpha_edge)
+    files["psd_truncated"] = files["psd_rgba_raw"][:-60]
+
+    qw, qh = 11, 7
+    pic_rgb = rng.randint(0, 256, size=(qh, qw, 4)).astype(np.uint8)
+    pic_runs = np.repeat(rng.randint(0, 256, size=(qh, 3, 4)).astype(np.uint8), 4, axis=1)[:, :qw]
+
+    def raw_rows(img, mask):
+        ch = [k for k in range(4) if mask & (0x80 >> k)]
+        return lambda y, k: bytes(img[y][:, ch].ravel())
+
+    def pure_rle_rows(img, mask):
+        ch = [k for k in range(4) if mask & (0x80 >> k)]
+
+        def f(y, k):
+            out, x = bytearray(), 0
+            while x < qw:
+                j = x
+                while j + 1 < qw and (img[y, j + 1, ch] == img[y, x, ch]).all() and j - x < 200:
+                    j += 1
+                out += bytes([j - x + 1]) + bytes(img[y, x, ch])
+                x = j + 1
+            return bytes(out)
+        return f
+
+    def mixed_rows(img, mask, long_run=False):
+        ch = [k for k in range(4) if mask & (0x80 >> k)]
+
+        def f(y, k):
+            out, x = bytearray(), 0
+            while x < qw:
+                j = x
+                while j + 1 < qw and (img[y, j + 1, ch] == img[y, x, ch]).all():
+                    j += 1
+                n = j - x + 1
+                if n >= 2:
+                    out += (bytes([128]) + struct.pack(">H", n) if long_run else bytes([127 + n])) + bytes(img[y, x, ch])
+                    x = j + 1
+                else:
+                    j = x
+                    while j + 1 < qw and not (j + 2 < qw and (img[y, j + 1, ch] == img[y, j + 2, ch]).all()):
+                        j += 1
+                    out += bytes([j - x]) + bytes(img[y, x:j + 1][:, ch].ravel())
+                    x = j + 1
+            return bytes(out)
+        return f
+
+    files["pic_rgb_raw"] = _pic(qw, qh, [(0, 0xE0)], raw_rows(pic_rgb, 0xE0))
+    files["pic_rgba_raw"] = _pic(qw, qh, [(0, 0xF0)], raw_rows(pic_rgb, 0xF0))
+    files["pic_rgb_pure_rle"] = _pic(qw, qh, [(1, 0xE0)], pure_rle_rows(pic_runs, 0xE0))
+    files["pic_rgb_mixed"] = _pic(qw, qh, [(2, 0xE0)], mixed_rows(pic_runs, 0xE0))
+    files["pic_rgb_mixed_long"] = _pic(qw, qh, [(2, 0xE0)], mixed_rows(pic_runs, 0xE0, long_run=True))
+    rgbf, af = mixed_rows(pic_runs, 0xE0), raw_rows(pic_rgb, 0x10)
+    files["pic_rgb_then_alpha"] = _pic(qw, qh, [(2, 0xE0), (0, 0x10)], lambda y, k: rgbf(y, k) if k == 0 else af(y, k))
+    files["pic_red_only"] = _pic(qw, qh, [(0, 0x80)], raw_rows(pic_rgb, 0x80))
+    files["pic_alpha_only"] = _pic(qw, qh, [(1, 0x10)], pure_rle_rows(pic_runs, 0x10))
+
+    hw, hh = 19, 6
+    lin = np.abs(rng.normal(size=(hh, hw, 3))) * np.array([0.02, 1.0, 30.0])[None, None, :]
+    lin[0, :5] = 0.0
+    lin[1, 3:12] = lin[1, 3]
+    e = _rgbe(lin)
+    files["hdr_rle"] = _hdr(e)
+    files["hdr_rle_runs_only"] = _hdr(np.repeat(e[:, :4], 5, axis=1)[:, :hw].copy(), raw_run_mix=False)
+    files["hdr_flat"] = _hdr(e, rle=False)
+    files["hdr_rgbe_magic"] = _hdr(e, magic=b"#?RGBE", extra=b"")
+    files["hdr_narrow_flat"] = _hdr(e[:, :7].copy(), rle=True)[: len(_hdr(e[:, :7].copy(), rle=False))] if False else _hdr(e[:, :7].copy(), rle=False)
+    files["hdr_bright_dark"] = _hdr(_rgbe(np.array([[[1e-6, 1e-3, 0.5], [1.0, 2.0, 1e4], [0.0, 0.0, 0.0], [0.9999, 1.0001, 0.18], [1e-9, 3e5, 7.0],
+                                                    [0.5, 0.5, 0.5], [0.25, 0.125, 0.0625], [123.0, 0.001, 1.0], [1e-12, 1e-12, 1e-12]]])), rle=True)
+    mixed = bytearray(_hdr(e))
+    files["hdr_second_row_not_rle"] = bytes(mixed[:mixed.index(b"+X %d\n" % hw) + len(b"+X %d\n" % hw)]) + _hdr(e)[len(_hdr(e[:0])) - 0:][:0] + b""  # placeholder, replaced below
+    head = _hdr(e[:1])                       # header + the first row, run-length coded
+    hdr_only = _hdr(e[:0]).replace(b"-Y 0", b"-Y %d" % hh)
+    first_row = head[len(_hdr(e[:0])):]
+    files["hdr_second_row_not_rle"] = hdr_only + first_row + e[1:].tobytes()
+    return files
+
+
+def make_legacy_decode(ref):
+    files = legacy_fixture_files()
+    out = {}
+    for name, data in files.items():
+        out[name + "/bytes"] = np.frombuffer(data, dtype=np.uint8)
+        for req in range(5):
+            arr, n = ref.load(data, req)
+            if arr is None:   # (a file the reference refuses: recorded as such)
+                out[f"{name}/n{req}"] = np.array([-1], dtype=np.int32)
+                continue
+            out[f"{name}/req{req}"] = arr
+            out[f"{name}/n{req}"] = np.array([n], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "legacy_decode.npz"), **out)
+    print("legacy_decode.npz:", len(files), "files")
+
+
 if __name__ == "__main__":
     make_frames()
     ref = stb_ref.load()
@@ -363,3 +657,4 @@ if __name__ == "__main__":
     make_png_encode(ref)
     make_jpeg_decode(ref)
     make_bmp_tga_decode(ref)
+    make_legacy_decode(ref)

@@ -1,4 +1,4 @@
-"""ASan/UBSan mutation fuzz of the native image decoders (PNG, JPEG, BMP, TGA, PNM) and the PNG
+"""ASan/UBSan mutation fuzz of the native image decoders (PNG, JPEG, BMP, TGA, PNM, GIF, PSD, PIC, HDR) and the PNG
 encoder round trip, CPU only.  Maps come from users' files: a malformed one may be refused, it
 must not corrupt memory."""
 import os
@@ -16,13 +16,14 @@ def test_decoders_survive_mutated_files(tmp_path):
     exe = str(tmp_path / "fuzz_image_io")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fwrapv", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-I" + SRC, os.path.join(ROOT, "tests", "fuzz_image_io.cpp"), os.path.join(SRC, "image_io.cpp"),
-           os.path.join(SRC, "jpeg_decode.cpp"), os.path.join(SRC, "bmp_tga_decode.cpp"), "-o", exe]
+           os.path.join(SRC, "jpeg_decode.cpp"), os.path.join(SRC, "bmp_tga_decode.cpp"), os.path.join(SRC, "legacy_formats.cpp"),
+           "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0 and "sanitize" in r.stderr:
         pytest.skip("no sanitizer runtime in this toolchain")
     assert r.returncode == 0, r.stderr
     files = []
-    for f in ("png_decode", "jpeg_decode", "bmp_tga_decode"):
+    for f in ("png_decode", "jpeg_decode", "bmp_tga_decode", "legacy_decode"):
         d = np.load(os.path.join(GOLDEN, f + ".npz"))
         for k in d.files:
             if k.endswith("/bytes"):

@@ -155,13 +155,48 @@ def test_bmp_tga_decode_matches_reference_stb(hmrm, stb_ref):
             hmrm.image_load_memory(blob, 3)
 
 
-def test_formats_not_decoded_natively_are_named(hmrm):
-    """GIF / PSD / Radiance HDR (which the reference's stb also reads) are refused with a message
-    that says so, not mistaken for another format."""
-    for blob, word in ((b"GIF89a" + bytes(40), "GIF"), (b"8BPS" + bytes(40), "PSD"), (b"#?RADIANCE\n" + bytes(40), "HDR")):
-        with pytest.raises(hmrm.HmrmError) as e:
-            hmrm.image_load_memory(blob, 3)
-        assert e.value.code == hmrm.HMRM_E_IMAGE and word in e.value.message
+def test_gif_psd_pic_hdr_decode_matches_reference_stb(hmrm, stb_ref):
+    """GIF, PSD, PIC and Radiance HDR maps (README.md "Options" lists them; csrc/legacy_formats.cpp): golden vectors
+    from the reference's own stb build for 43 hand-assembled files -- GIF 87a/89a, global / local palettes,
+    transparency, interlacing, sub-rectangles with and without a background index, dictionary resets, truncated data;
+    PSD raw / PackBits, 1-5 channels, 16 bits, partial alpha over the white matte; PIC raw / pure / mixed run-length
+    packets in several channel layouts; HDR run-length and flat scanlines, both magics -- for req_comp 0..4, plus the
+    live comparison where that build exists.  Files the reference refuses are refused."""
+    data = np.load(os.path.join(GOLDEN, "legacy_decode.npz"))
+    checked = refused = 0
+    names = _names(data)
+    assert {n.split("_")[0] for n in names} == {"gif", "gif87", "gif89", "psd", "pic", "hdr"}
+    for name in names:
+        blob = data[name + "/bytes"].tobytes()
+        for req in range(5):
+            want_n = int(data[f"{name}/n{req}"][0])
+            if want_n < 0:
+                with pytest.raises(hmrm.HmrmError) as e:
+                    hmrm.image_load_memory(blob, req)
+                assert e.value.code == hmrm.HMRM_E_IMAGE
+                refused += 1
+                continue
+            arr, n = hmrm.image_load_memory(blob, req)
+            exp = data[f"{name}/req{req}"]
+            assert n == want_n and arr.shape == exp.shape and np.array_equal(arr, exp), (name, req)
+            if stb_ref is not None:
+                live, n2 = stb_ref.load(blob, req)
+                assert n2 == n and np.array_equal(arr, live), (name, req)
+            checked += 1
+    assert checked >= 200 and refused >= 5
+
+
+def test_map_files_of_every_listed_format_through_config(hmrm, tmp_path):
+    """`heightmap x.gif` / `colormap x.psd` etc.: the config path hands any of the formats the reference's README
+    names to the decoders (main/hmap.cpp:320-321 req_comp 3, :341-342 req_comp 4)."""
+    data = np.load(os.path.join(GOLDEN, "legacy_decode.npz"))
+    for name, ext in (("gif_interlaced", "gif"), ("psd_rgba_rle", "psd"), ("pic_rgb_then_alpha", "pic"), ("hdr_rle", "hdr")):
+        p = tmp_path / f"map.{ext}"
+        p.write_bytes(data[name + "/bytes"].tobytes())
+        cfg = hmrm.Config().consume_string(f"heightmap {p}\ncolormap {p}\n")
+        assert np.array_equal(cfg.height_rgb(), data[name + "/req3"]), name
+        assert np.array_equal(cfg.color_rgba(), data[name + "/req4"]), name
+        cfg.close()
 
 
 def test_jpeg_heightmap_through_config(hmrm, tmp_path):
