@@ -78,7 +78,26 @@ constexpr int kLevelStep = HMRM_LEVEL_STEP;
 #define HMRM_MIP_LEVELS (HMRM_LEVEL_STEP == 2 ? 4 : 7)
 #endif
 constexpr int kMipLevels = HMRM_MIP_LEVELS;
-constexpr int mip_stride_shift(int l) { return 1 + kLevelStep * l; } // log2(S/2)
+// Windows of S cells are placed every S/2 cells on the levels below kDenseFrom (a ray always finds a window with at
+// least S/2 cells of room ahead) and every S/4 cells from that level on (at least 3S/4 of room: longer jumps for four
+// times the entries, which the coarse levels can afford and the 4-cell level, one entry per cell then, cannot --
+// C3, the one BASELINE config that uses it, got slower).  HMRM_DENSE_FROM: 0 = every level dense, 99 = none.
+#ifndef HMRM_DENSE_FROM
+#define HMRM_DENSE_FROM 1
+#endif
+constexpr int kDenseFrom = HMRM_DENSE_FROM;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+constexpr int win_strides(int l) { return l < kDenseFrom ? 2 : 4; }                        // strides per window
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+constexpr int win_cells(int l) { return 4 << (kLevelStep * l); }                             // S
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+constexpr int mip_stride_shift(int l) { return kLevelStep * l + (l < kDenseFrom ? 1 : 0); } // log2(S / strides per window)
 // Element of window (ix, iy) inside a plane (row-major with level 0's pitch; 8 x 4-window tiles per
 // 128-byte line were tried and change nothing, profiles/r02_experiments.txt).
 #if defined(__HIPCC__)

@@ -39,7 +39,7 @@ hipError_t launch_dilate3x3(const double *d_thr, int w, int h, double *d_dst, hi
 hipError_t launch_build_mip0(const double *d_thr, int map_w, int map_h, float *d_dst, int dst_w, int dst_h,
                              int pitch, hipStream_t stream);
 hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *d_dst, int dst_w, int dst_h,
-                               int pitch, hipStream_t stream);
+                               int pitch, int src_level, hipStream_t stream);
 // round-up-to-float of a double (the pyramid's rounding), on the host: for the whole-map element
 float round_up_to_float_host(double v);
 

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 				const double lateral = descent * __builtin_fmax(__builtin_fabs(sx), __builtin_fabs(sy)) * (GWM == 0 ? 1.0 : f.inv_grid_width);
 #pragma unroll
 				for (int l = kMipLevels - 1; l >= 0; l -= (kAdaptive ? 2 : 1)) // windows every 1 << hs cells: at least that much room ahead
-					lev = (l >= f.min_level && lateral <= (double)(1 << (kLevelStep * l + 1))) ? l : lev;
+					lev = (l >= f.min_level && lateral <= (double)((win_strides(l) - 1) << mip_stride_shift(l))) ? l : lev;
 			}
 			int cooldown = 0, fails = 0;
 			int jumps = 0; // successful jumps so far (kAdaptive)
@@ -236,10 +236,13 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						const bool exact = ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
 						const bool top = lev == kTopLevel;
 						// window (ix,iy) of level lev: S = 2<<hs cells wide, every 1<<hs cells.  The whole map is
-						// the one window of the top plane: with hs = 29 every in-grid cell has ix = iy = 0 and the
+						// the one window of the top plane: with hs = 28 every in-grid cell has ix = iy = 0 and the
 						// spans below come out as the map's, so nothing else treats that level specially.
-						const int hs = top ? 29 : kLevelStep * lev + 1;
-						int ix = (gx >> hs) - offx, iy = (gy >> hs) - offy;
+						// (levels below kDenseFrom: windows every half window, the others every quarter -- frame.hpp)
+						const bool sparse = lev < kDenseFrom;
+						const int hs = top ? 28 : kLevelStep * lev + (sparse ? 1 : 0);
+						const int back = sparse ? 1 : 3; // strides to step back when the cell index falls along the ray
+						int ix = (gx >> hs) - (offx ? back : 0), iy = (gy >> hs) - (offy ? back : 0);
 						ix = ix < 0 ? 0 : ix;
 						iy = iy < 0 ? 0 : iy;
 						const unsigned widx = ((unsigned)lev << f.mip_plane_shift) + (unsigned)index_2d(iy, f.mip_row, ix); // (= mip_index)
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						const double m = (double)mf; // (floats rounded up: also bounds every float / interpolated threshold)
 						const int wx0 = ix << hs, wy0 = iy << hs;
 						// (the last windows of a row / column hang over the map's edge: the usable span ends at the edge)
-						const int wspan_x = min(2 << hs, f.map_w - wx0), wspan_y = min(2 << hs, f.map_h - wy0);
+						const int wcells = top ? (1 << 30) : (4 << (kLevelStep * lev)); // window size S in cells
+						const int wspan_x = min(wcells, f.map_w - wx0), wspan_y = min(wcells, f.map_h - wy0);
 						const bool above = z >= m;
 						// Nothing below can succeed unless the ray is above this window's maximum: when no
 						// lane of the wave is, skip the estimate and the verification (the usual case in
@@ -499,35 +503,38 @@ __host__ __device__ __forceinline__ float round_up_to_float(double v) {
 }
 float round_up_to_float_host(double v) { return round_up_to_float(v); }
 
-// Level 0: window (ix,iy) = max of thr over cells [2ix, 2ix+4) x [2iy, 2iy+4), clipped; NaN ignored.
+// Level 0: window (ix,iy) = max of thr over the 4 x 4 cells from (S0 ix, S0 iy), clipped; NaN ignored.
 __global__ __launch_bounds__(256) void k_build_mip0(const double *__restrict__ thr, int map_w, int map_h,
                                                     float *__restrict__ dst, int dst_w, int dst_h, int pitch) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (int64_t)dst_w * dst_h) return;
 	const int ix = (int)(i % dst_w), iy = (int)(i / dst_w);
 	double m = -__builtin_huge_val();
-	for (int yy = 2 * iy; yy < 2 * iy + 4 && yy < map_h; ++yy)
-		for (int xx = 2 * ix; xx < 2 * ix + 4 && xx < map_w; ++xx) {
+	constexpr int S0 = 1 << mip_stride_shift(0); // level 0: 4-cell windows every S0 cells
+	for (int yy = S0 * iy; yy < S0 * iy + 4 && yy < map_h; ++yy)
+		for (int xx = S0 * ix; xx < S0 * ix + 4 && xx < map_w; ++xx) {
 			const double v = thr[(int64_t)yy * map_w + xx];
 			if (v > m) m = v;
 		}
 	dst[mip_index(ix, iy, pitch)] = round_up_to_float(m);
 }
 
-// Level l+1 from level l (H = stride of level l, windows 2H wide): with F = 2^kLevelStep the window
-// of 2FH cells at cell FH*i is the union of the level-l windows with indices F*i + {0, 2, .., 2(F-1)}.
+// Level l+1 from level l.  A level-l window is src_strides strides of level l wide; the window F = 2^kLevelStep times
+// as large that starts at stride i of level l+1 (= stride_ratio * i of level l) is the union of the level-l windows with
+// indices stride_ratio * i + {0, src_strides, .., src_strides * (F - 1)} per axis.
 __global__ __launch_bounds__(256) void k_build_mip_up(const float *__restrict__ src, int src_w, int src_h,
-                                                      float *__restrict__ dst, int dst_w, int dst_h, int pitch) {
+                                                      float *__restrict__ dst, int dst_w, int dst_h, int pitch,
+                                                      int stride_ratio, int src_strides) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (int64_t)dst_w * dst_h) return;
 	const int ix = (int)(i % dst_w), iy = (int)(i / dst_w);
 	constexpr int F = 1 << kLevelStep;
 	float m = -__builtin_huge_valf();
 	for (int b = 0; b < F; ++b) {
-		const int yy = F * iy + 2 * b;
+		const int yy = stride_ratio * iy + src_strides * b;
 		if (yy >= src_h) break;
 		for (int a = 0; a < F; ++a) {
-			const int xx = F * ix + 2 * a;
+			const int xx = stride_ratio * ix + src_strides * a;
 			if (xx >= src_w) break;
 			const float v = src[mip_index(xx, yy, pitch)];
 			if (v > m) m = v;
@@ -572,10 +579,11 @@ hipError_t launch_build_mip0(const double *d_thr, int map_w, int map_h, float *d
 }
 
 hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *d_dst, int dst_w, int dst_h,
-                               int pitch, hipStream_t stream) {
+                               int pitch, int src_level, hipStream_t stream) {
 	const int64_t n = (int64_t)dst_w * dst_h;
+	const int stride_ratio = 1 << (mip_stride_shift(src_level + 1) - mip_stride_shift(src_level));
 	hipLaunchKernelGGL(k_build_mip_up, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_src, src_w,
-	                   src_h, d_dst, dst_w, dst_h, pitch);
+	                   src_h, d_dst, dst_w, dst_h, pitch, stride_ratio, win_strides(src_level));
 	return hipGetLastError();
 }
 

@@ -1130,7 +1130,7 @@ def test_calibrated_and_pieced_launch_orders_never_change_a_pixel(gpu, oracle, c
                                   ortho_width=0.6, step_dist=0.25, bg=(4, 5, 6))
             ofb, *_ = oracle.render(oracle.make_cfg(cam, params, 200, 180), heights, cmap)
             buf = torch.zeros((cam.height, cam.width, 4), dtype=torch.uint8, device="cuda")
-            for rep in range(9):
+            for rep in range(12):
                 assert np.array_equal(scene.render(cam), ofb), (proj, rep)
                 scene.render_rows_device(cam, buf.data_ptr(), cam.width * 4, 0, cam.height, stream=st.cuda_stream)
                 torch.cuda.synchronize()

@@ -17,7 +17,7 @@ def bench(scene, label, cam):
         for p, mode in POLICIES:
             os.environ["HMRM_TILE_ORDER"] = mode
             if rnd == 0:
-                for _ in range(6):  # (calibration: plain, then up to three measured trials, settled)
+                for _ in range(9):  # (calibration: plain, then up to three trials measured twice, settled)
                     fb = scene.render(cam)
                     scene.bench_kernel_ms(cam, 3)
                 assert ref is None or np.array_equal(fb, ref), (label, p)
