@@ -54,6 +54,9 @@ def newest_per_dir(pattern):
     return sorted(best.values())
 
 
+# tools/prof_run.py spends its first launches on the launch-order calibration (measured launches, trial orders): those
+# dispatches are left out of the counter averages
+SKIP_FIRST = int(os.environ.get("PMC_SKIP_FIRST", "12"))
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in newest_per_dir(os.path.join(root, "**", "*_counter_collection.csv")):
     per_dispatch = collections.defaultdict(float)
@@ -62,8 +65,10 @@ for f in newest_per_dir(os.path.join(root, "**", "*_counter_collection.csv")):
         if product_kernel(r["Kernel_Name"]):
             per_dispatch[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
             names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+    skipped = set(sorted(names, key=int)[:SKIP_FIRST])
     for (disp, cname), v in per_dispatch.items():
-        per_kernel[names[disp]][cname].append(v)
+        if disp not in skipped:
+            per_kernel[names[disp]][cname].append(v)
 
 durations = collections.defaultdict(list)
 for f in newest_per_dir(os.path.join(root, "trace", "**", "*_kernel_trace.csv")):

@@ -12,12 +12,12 @@ out=gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$out"; mkdir -p "$out"
 timeout -k 10 300 python bench.py --workload $WL > "$out/bench.log" 2>&1
-# (one stream, launches back to back: the trace then holds the durations of single launches, which is what
-# roofline.kernel_ms of the bench line is; with frames in flight the kernels of the timed region overlap)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --workload $WL --no-cpu-baseline --frames-in-flight 1 > "$out/bench_under_rocprof.log" 2>&1
+# (the headline loop only -- one stream, launches back to back: the trace then holds the durations of single launches,
+# which is what roofline.kernel_ms of the bench line is; the secondary blocks overlap launches or render other cameras)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --workload $WL --no-cpu-baseline --no-secondary > "$out/bench_under_rocprof.log" 2>&1
 pmc() { # <dir> <counters...>
 	d=$1; shift
-	rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/$d" -- python tools/prof_run.py $WL leap 10 > /dev/null 2>&1
+	rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/$d" -- python tools/prof_run.py $WL leap 30 > /dev/null 2>&1
 }
 pmc fetch FETCH_SIZE TCC_HIT_sum
 pmc write WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
