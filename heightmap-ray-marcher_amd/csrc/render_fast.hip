@@ -684,7 +684,7 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 	{
 		static TimelineRec *host = nullptr;
 		static size_t cap = 0, used = 0;
-		static int gx = 0, gy = 0, rot = 0, ty = 0;
+		static int gx = 0, gy = 0, ty = 0, segs[7] = {0, 0, 0, 0, 0, 0, 0};
 		const size_t waves = (size_t)grid.x * grid.y * grid.z * (kBlockThreads / 64);
 		if (!stats) {
 			if (waves > cap) {
@@ -703,7 +703,7 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 						if (!path || !host) return;
 						(void)hipDeviceSynchronize();
 						if (FILE *fp = fopen(path, "wb")) {
-							const int hdr[6] = {gx, gy, kBlockThreads / 64, (int)used, rot, ty};
+							const int hdr[12] = {gx, gy, kBlockThreads / 64, (int)used, ty, segs[0], segs[1], segs[2], segs[3], segs[4], segs[5], segs[6]};
 							fwrite(hdr, sizeof hdr, 1, fp);
 							fwrite(host, sizeof(TimelineRec), used, fp);
 							fclose(fp);
@@ -714,7 +714,8 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 			used = waves;
 			gx = (int)grid.x;
 			gy = (int)(grid.y * grid.z);
-			rot = rows.seg_delta[0];
+			for (int k = 0; k < 3; ++k) segs[k] = rows.seg_first[k];
+			for (int k = 0; k < 4; ++k) segs[3 + k] = rows.seg_delta[k];
 			ty = tiles_y;
 		}
 	}

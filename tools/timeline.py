@@ -21,7 +21,9 @@ if os.environ.get("HMRM_TIMELINE_CHILD"):
     _, _, packed, _ = scene.render_stats(cam, per_pixel=True)
     os.environ.pop("HMRM_DIAG_ITERS")
     np.save(os.environ["HMRM_TIMELINE_FILE"] + ".trips.npy", (packed >> 16).astype(np.int64) + (packed & 0xffff).astype(np.int64))
-    print("kernel ms:", scene.bench_kernel_ms(cam, 30), flush=True)
+    for _ in range(12):  # (one at a time: the launch order of this camera settles)
+        scene.bench_kernel_ms(cam, 1)
+    print("kernel ms:", scene.bench_kernel_ms(cam, 10), flush=True)
     scene.close()
     sys.exit(0)
 out = "/tmp/hmrm_timeline.bin"
@@ -31,14 +33,19 @@ try:
 finally:
     subprocess.run(["bash", os.path.join(ROOT, "tools", "sweep_build.sh"), ""], check=True)
 raw = open(out, "rb").read()
-gx, gy, wpb, used, rot, tiles_y = struct.unpack("6i", raw[:24])
-rec = np.frombuffer(raw[24:], dtype=np.dtype([("t0", "<u8"), ("t1", "<u8"), ("xcc", "<u4"), ("pad", "<u4")]), count=used)
+gx, gy, wpb, used, tiles_y, *segs = struct.unpack("12i", raw[:48])
+seg_first, seg_delta = segs[:3], segs[3:]
+rot = seg_delta[0]
+rec = np.frombuffer(raw[48:], dtype=np.dtype([("t0", "<u8"), ("t1", "<u8"), ("xcc", "<u4"), ("pad", "<u4")]), count=used)
 steps = np.load(out + ".steps.npy").astype(np.int64)
 H, W = steps.shape
 # wave -> frame tile row: blocks are (x fastest, then y); a block holds wpb waves stacked vertically (8 rows each)
 blk = np.arange(used) // wpb
 by = blk // gx
-tile_row = (by + rot) % tiles_y
+delta = np.full(used, seg_delta[0])        # RowMap's grid row -> tile row map (device_common.hpp pixel_of_lane)
+for k in range(3):
+    delta = np.where(by >= seg_first[k], seg_delta[k + 1], delta)
+tile_row = (by + delta) % tiles_y
 wave_row0 = tile_row * (8 * wpb) + (np.arange(used) % wpb) * 8
 bx = blk % gx
 tiles = steps[:H // 8 * 8, :W // 8 * 8].reshape(H // 8, 8, W // 8, 8).sum(axis=(1, 3))
@@ -59,7 +66,7 @@ T = end.max()
 if os.environ.get("HMRM_TIMELINE_NPZ"):
     np.savez_compressed(os.environ["HMRM_TIMELINE_NPZ"], start=start.astype(np.float32), end=end.astype(np.float32), row=wave_row0.astype(np.int32),
                         col=bx.astype(np.int32), steps=wsteps, trips=wtrips.astype(np.int32), xcc=xcc.astype(np.int8))
-print(f"{name} [{extra}]: {used} waves, {int((wsteps > 0).sum())} marching; launch span {T:.0f} ticks of s_memrealtime (100 MHz: {T / 100:.1f} us); tile_rot {rot}")
+print(f"{name} [{extra}]: {used} waves, {int((wsteps > 0).sum())} marching; launch span {T:.0f} ticks of s_memrealtime (100 MHz: {T / 100:.1f} us); launch order pieces: first {seg_first}, delta {seg_delta}")
 print("per-XCD: waves, marching waves, last finish (fraction of the span)")
 for x in np.unique(xcc):
     m = xcc == x
