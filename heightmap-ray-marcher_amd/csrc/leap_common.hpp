@@ -66,12 +66,26 @@ __device__ __forceinline__ int index_2d(int row, int width, int col) {
 	return (int)(__umul24((unsigned)row, (unsigned)width) + (unsigned)col);
 }
 
+// HMRM_STEPS_LEFT (default 1): how long a coordinate stays inside its binade is counted, not re-estimated and
+// re-verified at every landing.  At a refresh the number of further steps that certainly stay strictly inside the
+// binade is estimated from the reciprocal, shortened by two and VERIFIED once (the position that many steps ahead
+// has the same sign and exponent and is off the boundary; every position before it then is too, the motion being
+// monotonic).  From there on every position of the ray in this binade is p_0 + j * delta exactly, j = steps taken
+// (leaped or real), so `left` just counts down; a jump of n <= left steps needs no exponent / mantissa test at its
+// landing point, and left < 0 says the binade has been left: refresh.  0 = round 2's scheme (key compare, three
+// binade rooms and three landing tests per attempt), kept for A/B runs.
+#ifndef HMRM_STEPS_LEFT
+#define HMRM_STEPS_LEFT 1
+#endif
+constexpr bool kStepsLeft = HMRM_STEPS_LEFT != 0;
+
 // Exact-stepping state of one coordinate inside its current binade.
 struct Axis {
 	double delta;  // p_{k+1} - p_k for every p of the binade (valid iff key matches)
 	double lim;    // binade boundary the coordinate is moving towards
 	double rdel;   // ~1/delta (signed); (lim - p) * rdel estimates the steps left
 	uint32_t key;  // sign+exponent bits (hi32 >> 20) the above was measured for
+	int left;      // kStepsLeft: further steps certain to stay strictly inside the binade; < 0: refresh needed
 };
 
 // Measure delta at p (see file header) from TWO real steps.  Off a rounding tie the
@@ -99,6 +113,15 @@ __device__ __forceinline__ void axis_refresh(Axis &a, double p, double s) {
 	const bool still = d == 0.0;              // the coordinate never moves (s == 0 or absorbed): unlimited room
 	a.lim = still ? p + 1.0 : lim;
 	a.rdel = still ? 0x1p40 : __builtin_amdgcn_rcp(d);
+	if (kStepsLeft) {
+		// steps that stay inside: the estimate shortened by two, at most 2^30, verified at its far end
+		int k = cvt_i32_sat((lim - p) * a.rdel) - 2;
+		k = k < 0 ? 0 : (k > (1 << 30) ? (1 << 30) : k);
+		const double pk = p + (double)k * d; // (exact: a multiple of u below 2^53 u)
+		const uint32_t hk = hi32(pk);
+		const int inside = (int)((hk >> 20) == (hp >> 20)) & (int)(((hk & 0xfffffu) | lo32(pk)) != 0u);
+		a.left = ok ? (still ? (1 << 30) : (inside ? k : 0)) : -1;
+	}
 }
 
 // p_n = p + n*delta is trustworthy iff it is still in p's binade with the same sign,

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 			ax.delta = ay.delta = az.delta = 0.0;
 			ax.lim = ay.lim = az.lim = 0.0;
 			ax.rdel = ay.rdel = az.rdel = 0.0;
+			ax.left = ay.left = az.left = -1; // (kStepsLeft: forces the first refresh)
 			// window choice: step back one half-window when the cell index decreases along the ray
 			const int offx = sx < 0.0 ? 1 : 0, offy = sy > 0.0 ? 1 : 0; // gy = trunc(-y/gw) falls when y grows
 			const double gwid = (GWM == 0) ? 1.0 : f.grid_width;
@@ -224,16 +225,21 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 					cooldown -= attempt ? 0 : 1;
 					if (attempt) {
 						diag.on_attempt();
-						diag.on_refresh_check(f, (hi32(x) >> 20) != ax.key, (hi32(y) >> 20) != ay.key, (hi32(z) >> 20) != az.key);
-						if ((hi32(x) >> 20) != ax.key) axis_refresh(ax, x, sx);
-						if ((hi32(y) >> 20) != ay.key) axis_refresh(ay, y, sy);
-						if ((hi32(z) >> 20) != az.key) axis_refresh(az, z, sz);
+						const bool stale_x = kStepsLeft ? ax.left < 0 : (hi32(x) >> 20) != ax.key;
+						const bool stale_y = kStepsLeft ? ay.left < 0 : (hi32(y) >> 20) != ay.key;
+						const bool stale_z = kStepsLeft ? az.left < 0 : (hi32(z) >> 20) != az.key;
+						diag.on_refresh_check(f, stale_x, stale_y, stale_z);
+						if (stale_x) axis_refresh(ax, x, sx);
+						if (stale_y) axis_refresh(ay, y, sy);
+						if (stale_z) axis_refresh(az, z, sz);
 						bool near0 = false;
 						double qx = cell_coord_fast<GWM>(x, f, near0), qy = cell_coord_fast<GWM>(-y, f, near0);
 						if (GWM == 2 && near0) { qx = x / f.grid_width; qy = -y / f.grid_width; }
 						const int gx = cvt_i32_sat(qx), gy = GWM == 0 ? cvt_i32_sat_neg(y) : cvt_i32_sat(qy);
 						const bool inb0 = (unsigned)gx < wlim && (unsigned)gy < hlim;
-						const bool exact = ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
+						const bool exact = kStepsLeft ? (ax.left | ay.left | az.left) >= 0
+						                              : ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
+						const int left_min = min(ax.left, min(ay.left, az.left)); // (kStepsLeft)
 						const bool top = lev == kTopLevel;
 						// window (ix,iy) of level lev: S = 2<<hs cells wide, every 1<<hs cells.  The whole map is
 						// the one window of the top plane: with hs = 28 every in-grid cell has ix = iy = 0 and the
@@ -259,18 +265,22 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						// lane of the wave is, skip the estimate and the verification (the usual case in
 						// the last, nearly empty waves of a launch, which set its duration).
 						double room = 0.0, room_b = 0x1p40, room_z = 0.0;
-						bool z_bound = false, ok = false, can = false;
+						bool z_bound = false, ok = false, can = false, binade_bound = false;
 						int n = 0;
 						if (__ballot(inb0 && exact && above) != 0ull) {
 							// estimates of the steps left before each constraint bites; rdel is signed like
 							// the motion, so every quotient is >= 0.  Only estimates: verified below.
 							const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;  // x edge ahead
 							const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid; // y edge ahead
-							room = (ax.lim - x) * ax.rdel;
-							room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
-							room = __builtin_fmin(room, (az.lim - z) * az.rdel);
-							room_b = room; // steps left inside the three binades
-							room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
+							if (kStepsLeft) {
+								room = sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40;
+							} else {
+								room = (ax.lim - x) * ax.rdel;
+								room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
+								room = __builtin_fmin(room, (az.lim - z) * az.rdel);
+								room_b = room; // steps left inside the three binades
+								room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
+							}
 							room = __builtin_fmin(room, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
 							room_z = sz < 0.0 ? (m - z) * az.rdel : 0x1p40;
 							z_bound = room_z < room;
@@ -278,6 +288,13 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							// (the saturating cast takes care of huge and negative estimates; the step budget caps the
 							// integer: a jump never takes more steps than the cap has left)
 							n = min(cvt_i32_sat(room * 0.998), budget) - 1;
+							if (kStepsLeft) { // (the binades' share is an exact count, not an estimate)
+								binade_bound = left_min <= n;
+								z_bound = z_bound & !binade_bound;
+								n = min(n, left_min);
+							} else {
+								binade_bound = room_b <= room;
+							}
 							can = inb0 && exact && above && n >= kMinLeap;
 							// landing point and its exact verification
 							const double nn = (double)n;
@@ -288,15 +305,22 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							const int gxn = cvt_i32_sat(qxn), gyn = GWM == 0 ? cvt_i32_sat_neg(yn) : cvt_i32_sat(qyn);
 							const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim; // (diagnostics only)
 							// (inside the window implies inside the grid: the spans were cut at the map's edge)
+							// (kStepsLeft: n <= left of every axis, so the landing point is inside the three binades by count)
 							ok = can && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
 							     (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
-							     axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn);
+							     (kStepsLeft || (axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn)));
 							diag.on_landing_refused(f, can && !ok, inbn,
 							                        (unsigned)(gxn - wx0) < (unsigned)wspan_x && (unsigned)(gyn - wy0) < (unsigned)wspan_y, zn >= m);
 							x = ok ? xn : x;
 							y = ok ? yn : y;
 							z = ok ? zn : z;
 							budget -= ok ? n : 0;
+							if (kStepsLeft) {
+								const int took = ok ? n : 0;
+								ax.left -= took;
+								ay.left -= took;
+								az.left -= took;
+							}
 						}
 						diag.on_attempt_done(f, inb0, exact, above, n < kMinLeap, z_bound, can, ok, n, lev);
 						// level policy (performance only; any policy gives the same pixels):
@@ -309,7 +333,6 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						//                                        level march 1 + finest_pause groups first
 						//   no lateral/binade room, not exact -> coarser (a bigger window has more room),
 						//                                        growing pause while attempts keep failing
-						const bool binade_bound = room_b <= room;
 						const bool height_limited = inb0 && exact && (!above || z_bound);
 						// levels per move: two while the ray is young (kAdaptive), then one
 						const bool young = kAdaptive && jumps <= kAdaptAfter;
@@ -457,6 +480,11 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 				x = X[kGroup - 1] + sx;
 				y = Y[kGroup - 1] + sy;
 				z = Z[kGroup - 1] + sz;
+				if (LEAP && kStepsLeft) { // kGroup real steps further inside (or out of) the binades
+					ax.left -= kGroup;
+					ay.left -= kGroup;
+					az.left -= kGroup;
+				}
 			}
 			if (STATS) my_steps = (unsigned long long)(unsigned)(budget0 - budget);
 		}
