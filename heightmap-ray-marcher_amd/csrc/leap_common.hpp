@@ -114,8 +114,9 @@ __device__ __forceinline__ void axis_refresh(Axis &a, double p, double s) {
 	a.lim = still ? p + 1.0 : lim;
 	a.rdel = still ? 0x1p40 : __builtin_amdgcn_rcp(d);
 	if (kStepsLeft) {
-		// steps that stay inside: the estimate shortened by two, at most 2^30, verified at its far end
-		int k = cvt_i32_sat((lim - p) * a.rdel) - 2;
+		// steps that stay inside: the estimate (the reciprocal is good to 2^-24: shortened by 2^-22 of itself and by
+		// two steps), at most 2^30, verified at its far end
+		int k = cvt_i32_sat((lim - p) * a.rdel * (1.0 - 0x1p-22)) - 2;
 		k = k < 0 ? 0 : (k > (1 << 30) ? (1 << 30) : k);
 		const double pk = p + (double)k * d; // (exact: a multiple of u below 2^53 u)
 		const uint32_t hk = hi32(pk);

@@ -117,3 +117,56 @@ def test_absorbed_and_zero_steps():
     for p in (0.0, 1e-300, float("inf"), float("nan")):
         L.axis_refresh(a, p, 0.25)
         assert a.key == 0xFFFFFFFF
+
+
+def test_steps_left_count_is_a_safe_bound():
+    """kStepsLeft (csrc/leap_common.hpp): after a refresh, every one of the next `left` positions -- the reference's
+    sequential p += s -- equals p + j * delta bit for bit, stays inside the binade and off its boundary; so a jump of
+    n <= left steps needs no test at its landing point.  Random and adversarial starts (close to either boundary, exact
+    ties, reciprocal errors of either sign at the measured 2^-24); brute force against sequential stepping."""
+    rng = random.Random(7)
+    checked = long_runs = 0
+    for trial in range(6000):
+        e = rng.randint(-3, 11)
+        lo = math.ldexp(1.0, e)
+        kind = trial % 4
+        if kind == 0:      # anywhere in the binade; now and then with a tiny step (10^6 .. 10^9 steps to the boundary)
+            p = lo * (1.0 + rng.random())
+            s = math.ldexp(rng.random() - 0.5, e - rng.randint(2, 9) - (rng.choice((20, 25, 30)) if trial % 16 == 0 else 0))
+        elif kind == 1:    # a few steps before the upper boundary, moving up
+            s = math.ldexp(rng.random() + 0.01, e - rng.randint(3, 10))
+            p = 2 * lo - s * rng.uniform(0.0, 30.0)
+        elif kind == 2:    # a few steps above the lower boundary, moving down
+            s = -math.ldexp(rng.random() + 0.01, e - rng.randint(3, 10))
+            p = lo - s * rng.uniform(0.0, 30.0)
+        else:              # exact rounding ties
+            m = rng.randint(2 ** 52 + 2 ** 30, 2 ** 53 - 2 ** 30)
+            p = math.ldexp(float(m), e - 52)
+            s = _tie_step(p, rng.randint(1, 2 ** 20), rng.choice((1.0, -1.0)))
+        if not (lo <= p < 2 * lo):
+            continue
+        sign = rng.choice((1.0, -1.0))
+        p, s = sign * p, sign * s
+        a = L.Axis()
+        L.axis_refresh(a, p, s, rcp_err=rng.choice((0.0, 2.0 ** -24, -2.0 ** -24, rng.uniform(-1, 1) * 2.0 ** -24)))
+        if a.left < 0:
+            continue
+        q, key = p, L.hi32(p) >> 20
+        for j in range(1, min(a.left, 3000) + 1):
+            q = q + s
+            assert bits(q) == bits(p + float(j) * a.delta), (p, s, j, a.left)
+            assert (L.hi32(q) >> 20) == key and ((L.hi32(q) & 0xFFFFF) != 0 or L.lo32(q) != 0 or a.delta == 0.0), (p, s, j)
+        if a.left <= 3000 and a.delta != 0.0:
+            # ... and the count is tight: within a few steps of the true number that stay inside
+            more = 0
+            while (L.hi32(q + s) >> 20) == key and more < 10:
+                q = q + s
+                more += 1
+            assert more <= 6, (p, s, a.left, more)
+        elif a.delta != 0.0:
+            # long stays (tiny steps): never given up, and short by no more than 2^-21 of the stay plus a few steps
+            true_left = abs((a.lim - p) / a.delta)
+            assert a.left > 0 and (a.left == 1 << 30 or true_left - a.left <= true_left * 2.0 ** -21 + 8), (p, s, a.left, true_left)  # (capped at 2^30)
+        checked += 1
+        long_runs += a.left > 3000
+    assert checked > 3000 and long_runs > 100
