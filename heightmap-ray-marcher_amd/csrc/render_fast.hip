@@ -18,18 +18,23 @@
 //     maxima over the hit thresholds then lets a ray jump over n steps at once when
 //     all n skipped positions provably (a) stay inside the window whose maximum was
 //     looked up and (b) stay at or above that maximum (no hit possible: hmap.cpp:1016
-//     needs z < threshold), with (c) all three coordinates inside their binades.  The
-//     jump length is only ESTIMATED (approximate reciprocals); the landing point is
-//     then VERIFIED with exact tests (cell inside the window, z >= max, exponent /
-//     sign / mantissa of each coordinate), and monotonicity of each coordinate in k
-//     extends the verification from the landing point to every skipped position.  A
-//     failed verification just means "no jump".  Skipped positions are counted as
-//     steps: each was inside the grid, so the reference executed its height load there.
+//     needs z < threshold), with (c) all three coordinates inside their binades.
+//     (a) and (b): the jump length is only ESTIMATED (approximate reciprocals); the landing
+//     point is then VERIFIED with exact tests (cell inside the window, z >= max), and
+//     monotonicity of each coordinate in k extends the verification from the landing point to
+//     every skipped position.  A failed verification just means "no jump".
+//     (c): how many further steps stay strictly inside a coordinate's binade is established ONCE
+//     per binade (axis_refresh: estimate, shortened, verified at its far end) and counted down
+//     with every step leaped or marched (Axis::left): a jump never exceeds the three counts.
+//     Skipped positions are counted as steps: each was inside the grid, so the reference
+//     executed its height load there.
 //
 // Pyramid layout (built by k_build_mip*): level l holds maxima of S x S-cell windows,
-// S = 4, 8, 16, .. 256, placed every S/2 cells (overlapping), so that a ray can always pick
-// a window in which it has at least S/2 cells of room ahead.  Values are floats
-// rounded UP (a larger bound is always safe).  Above them: the whole map, the one window of a top plane.
+// S = 4, 8, 16, .. 256, placed every S/2 cells on the 4-cell level and every S/4 cells above it
+// (overlapping), so that a ray can always pick a window in which it has at least S/2 (3S/4) cells of
+// room ahead.  Values are floats rounded UP (a larger bound is always safe).  Above them: the whole
+// map, the one window of a top plane.  A ray moves two levels at a time until it has made kAdaptAfter
+// jumps, then one at a time (performance only: any level sequence gives the same pixels).
 #ifdef HMRM_TIMELINE
 #include <cstdio>
 #include <cstdlib>
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						                              : ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
 						const int left_min = min(ax.left, min(ay.left, az.left)); // (kStepsLeft)
 						const bool top = lev == kTopLevel;
-						// window (ix,iy) of level lev: S = 2<<hs cells wide, every 1<<hs cells.  The whole map is
+						// window (ix,iy) of level lev: S = 4 << lev cells wide, one every 1<<hs cells.  The whole map is
 						// the one window of the top plane: with hs = 28 every in-grid cell has ix = iy = 0 and the
 						// spans below come out as the map's, so nothing else treats that level specially.
 						// (levels below kDenseFrom: windows every half window, the others every quarter -- frame.hpp)
