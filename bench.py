@@ -277,7 +277,7 @@ def main():
         return dt, total_over_ranks(sum(steps_of[k] for k in mine[n_warm:])), check
 
     # Untimed, before any warm-up step: the library calibrates the launch order of a camera it sees repeatedly from a few
-    # measured launches (csrc/api.cpp plan_order_from_measurement; each needs the previous one finished, which a
+    # measured launches (csrc/launch_order.cpp plan_order_from_measurement; each needs the previous one finished, which a
     # renderer that presents its frames does by itself and a loop that queues hundreds of launches ahead does not):
     # a dozen launches of the static pose with a synchronisation in between, then 50 more so that the GPUs enter the
     # timed region at steady clocks.

@@ -163,7 +163,7 @@ lib, EXPORTED_SYMBOLS = _load()
 # Device + launch sources: a PMC summary (profiles/traffic.json) is only valid for the kernel it was
 # collected on, so it carries this hash and bench.py refuses one that does not match the tree.
 KERNEL_SOURCES = ("render_fast.hip", "leap_common.hpp", "leap_diag.hpp", "render.hip", "device_common.hpp", "frame.hpp",
-                  "render.hpp", "api.cpp", "camera.cpp", "Makefile")
+                  "render.hpp", "api.cpp", "launch_order.cpp", "launch_order.hpp", "camera.cpp", "Makefile")
 
 
 def kernel_src_sha() -> str:
@@ -202,7 +202,7 @@ def set_device(i: int):
 
 # The library reads its environment knobs once per scene.  Tests and tools flip them
 # on live scenes, so the Python wrappers re-read them when one changed since the scene last looked.
-_ENV_KNOBS = ("HMRM_KERNEL", "HMRM_STEP_CAP", "HMRM_TILE_ORDER", "HMRM_DIAG_ITERS", "HMRM_MIN_LEVEL", "HMRM_TILE_SEGMENTS", "HMRM_ORDER_SPLIT")
+_ENV_KNOBS = ("HMRM_KERNEL", "HMRM_STEP_CAP", "HMRM_TILE_ORDER", "HMRM_DIAG_ITERS", "HMRM_MIN_LEVEL", "HMRM_TILE_SEGMENTS", "HMRM_ORDER_VERBOSE")
 
 
 def _env_snapshot():

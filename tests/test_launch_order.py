@@ -1,4 +1,4 @@
-"""Host logic of the launch-order calibration (csrc/api.cpp plan_order_from_measurement / set_tile_order; CPU only).
+"""Host logic of the launch-order calibration (csrc/launch_order.cpp plan_order_from_measurement / set_tile_order; CPU only).
 The plan is scheduling -- it can never change a pixel -- but it must always be a PERMUTATION of the tile rows, and on
 a measured profile like BASELINE config C3's (tools/timeline.py) it must move the bottom of the hot range in front of
 its middle."""

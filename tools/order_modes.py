@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch-order policies side by side (interleaved): HMRM_TILE_ORDER=1 plain rotation, 2 rotation calibrated from
-measurement (api.cpp plan_order_from_measurement; HMRM_ORDER_VERBOSE=1 reports each calibration on stderr).
+measurement (launch_order.cpp plan_order_from_measurement; HMRM_ORDER_VERBOSE=1 reports each calibration on stderr).
 BASELINE workloads and other cameras over the 4096^2 scene.  usage: order_modes.py [workloads...]"""
 import importlib, os, sys
 import numpy as np
