@@ -628,6 +628,21 @@ def legacy_fixture_files():
     hdr_only = _hdr(e[:0]).replace(b"-Y 0", b"-Y %d" % hh)
     first_row = head[len(_hdr(e[:0])):]
     files["hdr_second_row_not_rle"] = hdr_only + first_row + e[1:].tobytes()
+    # more corners: a 16-bit PSD with PackBits rows (taken as bytes), PSD / flat HDR cut short, an HDR too wide for
+    # run-length scanlines, a header line longer than the reader's buffer, GIF code sizes 1 and 3, a GIF without trailer
+    files["psd_16bit_rle"] = _psd([np.repeat(rng.randint(0, 256, size=(ph, 4)).astype(np.uint8), 4, axis=1)[:, :pw] for _ in range(3)], depth=16, rle=True)
+    files["psd_rle_truncated"] = files["psd_rgba_rle"][:-25]
+    # (a PIC cut short, a PIC that ends after its header and an HDR whose run-length data ends early are NOT here: the
+    # reference's loader crashes on the first two and never returns from the third -- tests/test_image_io.py only checks
+    # that this library refuses them)
+    files["hdr_flat_truncated"] = files["hdr_flat"][:-30]
+    files["hdr_long_header_line"] = _hdr(e, extra=b"COMMENT=" + b"x" * 1500 + b"\n")
+    wide = np.tile(e[:1, :16], (1, 2050, 1))[:, :32770].copy()      # width >= 32768: flat data whatever the file says
+    files["hdr_too_wide_for_rle"] = _hdr(wide, rle=False)
+    files["gif_code_size_1"] = _gif(7, 3, [dict(rect=(0, 0, 7, 3), indices=(noisy[:3, :7] & 1).ravel(), min_bits=1)], global_pal=pal8[:6])
+    files["gif_code_size_3"] = _gif(9, 9, [dict(rect=(0, 0, 9, 9), indices=(noisy[:9, :9] & 7).ravel(), min_bits=3, interlace=True)], global_pal=pal8[:24])
+    files["gif_no_trailer"] = _gif(w, h, [dict(rect=(0, 0, w, h), indices=smooth.ravel())], global_pal=pal8, trailer=False)
+    files["gif_zero_width_image"] = _gif(w, h, [dict(rect=(3, 3, 0, 4), indices=[])], global_pal=pal8, bg=5)
     return files
 
 

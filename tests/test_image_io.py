@@ -157,7 +157,7 @@ def test_bmp_tga_decode_matches_reference_stb(hmrm, stb_ref):
 
 def test_gif_psd_pic_hdr_decode_matches_reference_stb(hmrm, stb_ref):
     """GIF, PSD, PIC and Radiance HDR maps (README.md "Options" lists them; csrc/legacy_formats.cpp): golden vectors
-    from the reference's own stb build for 43 hand-assembled files -- GIF 87a/89a, global / local palettes,
+    from the reference's own stb build for 52 hand-assembled files -- GIF 87a/89a, global / local palettes,
     transparency, interlacing, sub-rectangles with and without a background index, dictionary resets, truncated data;
     PSD raw / PackBits, 1-5 channels, 16 bits, partial alpha over the white matte; PIC raw / pure / mixed run-length
     packets in several channel layouts; HDR run-length and flat scanlines, both magics -- for req_comp 0..4, plus the
@@ -183,7 +183,14 @@ def test_gif_psd_pic_hdr_decode_matches_reference_stb(hmrm, stb_ref):
                 live, n2 = stb_ref.load(blob, req)
                 assert n2 == n and np.array_equal(arr, live), (name, req)
             checked += 1
-    assert checked >= 200 and refused >= 5
+    assert checked >= 250 and refused >= 5
+    # files on which the reference's loader crashes or never returns: refused here, promptly
+    for blob in (data["pic_rgb_mixed/bytes"].tobytes()[:-9], data["pic_rgb_raw/bytes"].tobytes()[:104],
+                 data["hdr_rle/bytes"].tobytes()[:-40]):
+        for req in (0, 3, 4):
+            with pytest.raises(hmrm.HmrmError) as e:
+                hmrm.image_load_memory(blob, req)
+            assert e.value.code == hmrm.HMRM_E_IMAGE
 
 
 def test_map_files_of_every_listed_format_through_config(hmrm, tmp_path):
