@@ -148,6 +148,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
                                                      int tiles_y, StatsOut st) {
 	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
 	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
+	const float *__restrict__ mip = BILINEAR ? f.mipbuf_bil : f.mipbuf; // the pyramid this sampling mode leaps on
 	const PixelId pid = pixel_of_lane(f, rows, tiles_y);
 #ifdef HMRM_TIMELINE
 	const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						iy = iy < 0 ? 0 : iy;
 						const unsigned widx = ((unsigned)lev << f.mip_plane_shift) + (unsigned)index_2d(iy, f.mip_row, ix); // (= mip_index)
 						diag.load_begin(f, 17);
-						float mf = (BILINEAR ? f.mipbuf_bil : f.mipbuf)[inb0 ? widx : 0u];
+						// (a 32-bit byte offset from the pyramid's base: at most 8 planes of 2^27 floats, api.cpp's map limit)
+						float mf = *(const float *)((const char *)mip + (size_t)((inb0 ? widx : 0u) * 4u));
 						diag.load_end(f, 17, mf);
 						const double m = (double)mf; // (floats rounded up: also bounds every float / interpolated threshold)
 						const int wx0 = ix << hs, wy0 = iy << hs;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 				// --------------------------------------------- speculative group
 				diag.on_group();
 				double X[kGroup], Y[kGroup], Z[kGroup], T[kGroup];
-				int cell[kGroup];
+				unsigned cell[kGroup]; // (unsigned: the 64-bit address needs no sign extension)
 				bool inb[kGroup];
 				X[0] = x; Y[0] = y; Z[0] = z;
 #pragma unroll
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 					const double qx = QX[j], qy = QY[j];
 					const int gx = cvt_i32_sat(qx), gy = GWM == 0 ? cvt_i32_sat_neg(Y[j]) : cvt_i32_sat(qy); // hmap.cpp:1001-1004
 					inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;      // hmap.cpp:1006-1011
-					cell[j] = inb[j] ? index_2d(gy, f.map_w, gx) : 0;
+					cell[j] = inb[j] ? (unsigned)index_2d(gy, f.map_w, gx) : 0u;
 				}
 				diag.load_begin(f, 18);
 				if (BILINEAR) {
@@ -415,12 +417,17 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 					}
 				} else {
 #pragma unroll
-					for (int j = 0; j < kGroup; ++j) T[j] = F32 ? (double)thr32[cell[j]] : thr[cell[j]]; // hmap.cpp:1013-1014 (+ c0.z)
+					// (32-bit byte offsets from the table's base -- api.cpp caps maps at 2^29 cells -- so that the loads can
+					// take the base from scalar registers: no 64-bit address arithmetic per sample)
+					for (int j = 0; j < kGroup; ++j)
+						T[j] = F32 ? (double)*(const float *)((const char *)thr32 + (size_t)(cell[j] * 4u))
+						           : *(const double *)((const char *)thr + (size_t)(cell[j] * 8u)); // hmap.cpp:1013-1014 (+ c0.z)
 				}
 				if (kGroup == 4) diag.load_end(f, 18, T[0], T[1], T[2], T[3]);
 				if (budget >= kGroup) {
 					// in order: the first position that leaves the grid (:1006) or hits (:1016) ends the ray
-					int first = kGroup, hit_cell = 0, hit_j = 0;
+					int first = kGroup, hit_j = 0;
+					unsigned hit_cell = 0u;
 					bool hit = false;
 #pragma unroll
 					for (int j = kGroup - 1; j >= 0; --j) { // (selects, last write = earliest position)
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 								qxh = hit_j == j ? QX[j] : qxh;
 								qyh = hit_j == j ? QY[j] : qyh;
 							}
-							rgba = shade_hit_bilinear(f, cmap, hit_cell, bil_setup(qxh, qyh, f.map_w, f.map_h));
+							rgba = shade_hit_bilinear(f, cmap, (int)hit_cell, bil_setup(qxh, qyh, f.map_w, f.map_h));
 						} else {
 							rgba = shade_hit(f, cmap[hit_cell]);
 						}
