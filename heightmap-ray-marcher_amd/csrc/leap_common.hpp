@@ -78,6 +78,15 @@ __device__ __forceinline__ int index_2d(int row, int width, int col) {
 #define HMRM_STEPS_LEFT 1
 #endif
 constexpr bool kStepsLeft = HMRM_STEPS_LEFT != 0;
+// HMRM_CROSS (default 1; needs HMRM_STEPS_LEFT): a jump ends with ONE real step p + s after its multiplied ones.  When a
+// binade's end cut the jump short that step is the one that crosses it, so no group of real steps has to be marched just
+// to get a coordinate into its next binade.  The count below then is taken as tight as the estimate allows (no two
+// steps of allowance -- its far end is verified anyway), so that the step after the last counted one does cross
+// (tests/test_leap_math.py: in 99.99 % of random cases).  0 = jumps of multiplied steps only, kept for A/B runs.
+#ifndef HMRM_CROSS
+#define HMRM_CROSS 1
+#endif
+constexpr bool kCross = kStepsLeft && HMRM_CROSS != 0;
 
 // Exact-stepping state of one coordinate inside its current binade.
 struct Axis {
@@ -114,9 +123,10 @@ __device__ __forceinline__ void axis_refresh(Axis &a, double p, double s) {
 	a.lim = still ? p + 1.0 : lim;
 	a.rdel = still ? 0x1p40 : __builtin_amdgcn_rcp(d);
 	if (kStepsLeft) {
-		// steps that stay inside: the estimate (the reciprocal is good to 2^-24: shortened by 2^-22 of itself and by
-		// two steps), at most 2^30, verified at its far end
-		int k = cvt_i32_sat((lim - p) * a.rdel * (1.0 - 0x1p-22)) - 2;
+		// steps that stay inside: the estimate (the reciprocal is good to 2^-24: shortened by 2^-22 of itself, so it is
+		// below the true quotient and its integer part is at most the count wanted; without kCross two steps fewer),
+		// at most 2^30, verified at its far end
+		int k = cvt_i32_sat((lim - p) * a.rdel * (1.0 - 0x1p-22)) - (kCross ? 0 : 2);
 		k = k < 0 ? 0 : (k > (1 << 30) ? (1 << 30) : k);
 		const double pk = p + (double)k * d; // (exact: a multiple of u below 2^53 u)
 		const uint32_t hk = hi32(pk);

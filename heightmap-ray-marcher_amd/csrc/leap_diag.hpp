@@ -18,6 +18,7 @@ struct LoopDiag<false> {
 	__device__ __forceinline__ void on_landing_refused(const DevFrame &, bool, bool, bool, bool) {}
 	__device__ __forceinline__ void on_attempt_done(const DevFrame &, bool, bool, bool, bool, bool, bool, bool, int, int) {}
 	__device__ __forceinline__ void on_trip(const DevFrame &, bool, bool) {}
+	__device__ __forceinline__ void on_bounds(bool, bool) {}
 	__device__ __forceinline__ void on_group() {}
 	__device__ __forceinline__ void load_begin(const DevFrame &, int) {}
 	__device__ __forceinline__ void load_end(const DevFrame &, int, float &) {}
@@ -33,9 +34,14 @@ struct LoopDiag<true> {
 	unsigned long long x0 = 0, x1 = 0, x2 = 0, x3 = 0; // meaning depends on diag_mode
 	unsigned long long t_start = 0, t_load = 0;
 	bool attempted = false; // this trip ran the attempt block
+	bool jumped = false, at_binade = false; // this trip's attempt: succeeded / was limited by a binade's end
 
 	__device__ __forceinline__ void start() { t_start = __builtin_amdgcn_s_memtime(); }
-	__device__ __forceinline__ void begin_trip() { attempted = false; }
+	__device__ __forceinline__ void begin_trip() { attempted = jumped = at_binade = false; }
+	__device__ __forceinline__ void on_bounds(bool ok, bool binade_bound) {
+		jumped = ok;
+		at_binade = binade_bound;
+	}
 	__device__ __forceinline__ void on_attempt() {
 		++attempts;
 		attempted = true;
@@ -89,6 +95,12 @@ struct LoopDiag<true> {
 	}
 	// modes 12-15: wave-level view of the loop -- who runs which block, with how many useful lanes
 	__device__ __forceinline__ void on_trip(const DevFrame &f, bool leap_enabled, bool skip_group) {
+		if (f.diag_mode == 20 && !skip_group) { // mode 20: what came before a group (per lane)
+			x0 += (attempted && jumped && at_binade) ? 1u : 0u;   // a jump that stopped at a binade's end
+			x1 += (attempted && !jumped && at_binade) ? 1u : 0u;  // an attempt with no binade room for a jump
+			x2 += !attempted ? 1u : 0u;                           // no attempt (pause after failures)
+			x3 += (attempted && !at_binade) ? 1u : 0u;            // any other attempt
+		}
 		if (f.diag_mode < 12 || f.diag_mode > 15) return;
 		const unsigned long long act = __ballot(true);
 		const unsigned long long att = __ballot(leap_enabled && attempted);

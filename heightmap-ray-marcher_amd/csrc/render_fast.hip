@@ -25,7 +25,12 @@
 //     every skipped position.  A failed verification just means "no jump".
 //     (c): how many further steps stay strictly inside a coordinate's binade is established ONCE
 //     per binade (axis_refresh: estimate, shortened, verified at its far end) and counted down
-//     with every step leaped or marched (Axis::left): a jump never exceeds the three counts.
+//     with every step leaped or marched (Axis::left): the multiplied part of a jump never exceeds the
+//     three counts.  A jump of n steps is n - 1 multiplied steps and then ONE real step fl(p + s) from that
+//     exact position (HMRM_CROSS): where a binade's end cut the jump short, that step is the one
+//     that carries the coordinate into its next binade -- otherwise a whole group of real steps would
+//     have to be marched at every binade boundary (half of all groups before this was done).  The
+//     end point after the real step is what (a) and (b) are verified for.
 //     Skipped positions are counted as steps: each was inside the grid, so the reference
 //     executed its height load there.
 //
@@ -296,16 +301,22 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							// integer: a jump never takes more steps than the cap has left)
 							n = min(cvt_i32_sat(room * 0.998), budget) - 1;
 							if (kStepsLeft) { // (the binades' share is an exact count, not an estimate)
-								binade_bound = left_min <= n;
+								// (kCross: the jump's last step is a real one and may leave the binade)
+								const int left_lim = left_min + (kCross ? 1 : 0);
+								binade_bound = left_lim <= n;
 								z_bound = z_bound & !binade_bound;
-								n = min(n, left_min);
+								n = min(n, left_lim);
 							} else {
 								binade_bound = room_b <= room;
 							}
 							can = inb0 && exact && above && n >= kMinLeap;
 							// landing point and its exact verification
-							const double nn = (double)n;
-							const double xn = x + nn * ax.delta, yn = y + nn * ay.delta, zn = z + nn * az.delta;
+							// (kCross: n - 1 steps by multiplication, all inside the three binades by count, then one real step
+							// from that exact position.  Coordinates move monotonically, so the tests of the end point below
+							// hold for every position before it.)
+							const double nn = (double)(kCross ? n - 1 : n);
+							const double xm = x + nn * ax.delta, ym = y + nn * ay.delta, zm = z + nn * az.delta;
+							const double xn = kCross ? xm + sx : xm, yn = kCross ? ym + sy : ym, zn = kCross ? zm + sz : zm;
 							bool nearn = false;
 							double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
 							if (GWM == 2 && nearn) { qxn = xn / f.grid_width; qyn = -yn / f.grid_width; }
@@ -330,11 +341,12 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							}
 						}
 						diag.on_attempt_done(f, inb0, exact, above, n < kMinLeap, z_bound, can, ok, n, lev);
+						diag.on_bounds(ok, binade_bound);
 						// level policy (performance only; any policy gives the same pixels):
 						//   window crossed                    -> coarser next time, if the height bound of this
 						//                                        level left room for a window kUpRatio times
 						//                                        longer (a coarser maximum is no lower)
-						//   jump ended at a binade boundary   -> same level, and march a group first
+						//   jump ended at a binade boundary   -> same level (without kCross: and march a group first)
 						//   height bound was the limit        -> finer; without a jump retry at once (the
 						//     (z < max, or z-room smallest)      level strictly decreases); at the finest
 						//                                        level march 1 + finest_pause groups first
@@ -369,7 +381,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						// retry one level down without marching; after a jump look at the next window straight
 						// away -- unless the jump stopped at a binade boundary: only real steps cross it,
 						// another attempt here would just fail
-						skip_group = (hl & !ok & !at_finest) | (ok & !binade_bound);
+						// (kCross: the jump's last step has crossed it)
+						skip_group = (hl & !ok & !at_finest) | (ok & (kCross | !binade_bound));
 					}
 				}
 				diag.on_trip(f, LEAP, skip_group);

@@ -36,7 +36,7 @@ def cvt_i32_sat(v: float) -> int:
     return max(-2 ** 31, min(2 ** 31 - 1, int(v)))
 
 
-def axis_refresh(a: Axis, p: float, s: float, rcp_err: float = 0.0) -> None:
+def axis_refresh(a: Axis, p: float, s: float, rcp_err: float = 0.0, short: int = 2) -> None:
     p1 = p + s
     p2 = p1 + s
     hp, hp1, hp2 = hi32(p), hi32(p1), hi32(p2)
@@ -54,14 +54,14 @@ def axis_refresh(a: Axis, p: float, s: float, rcp_err: float = 0.0) -> None:
         a.lim = -lim_abs if (hp >> 31) else lim_abs
         a.rdel = 1.0 / d  # the device uses an approximate reciprocal; only an estimate anyway
     # kStepsLeft (leap_common.hpp): further steps certain to stay strictly inside the binade -- the estimate, which
-    # the device forms with a reciprocal good to 2^-24 (rcp_err models that), shortened by 2^-22 of itself and by two steps,
-    # and verified at its far end
+    # the device forms with a reciprocal good to 2^-24 (rcp_err models that), shortened by 2^-22 of itself and by `short`
+    # steps (2; 0 in HMRM_CROSS builds), and verified at its far end
     if not ok:
         a.left = -1
     elif d == 0.0:
         a.left = 1 << 30
     else:
-        k = max(0, min(1 << 30, cvt_i32_sat((a.lim - p) * (a.rdel * (1.0 + rcp_err)) * (1.0 - 2.0 ** -22)) - 2))
+        k = max(0, min(1 << 30, cvt_i32_sat((a.lim - p) * (a.rdel * (1.0 + rcp_err)) * (1.0 - 2.0 ** -22)) - short))
         pk = p + float(k) * d
         inside = (hi32(pk) >> 20) == (hp >> 20) and ((hi32(pk) & 0xFFFFF) != 0 or lo32(pk) != 0)
         a.left = k if inside else 0

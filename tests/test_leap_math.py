@@ -12,6 +12,7 @@ directions, absorbed steps, negative coordinates.
 import math
 import random
 import struct
+import pytest
 
 import leap_model as L
 
@@ -119,8 +120,9 @@ def test_absorbed_and_zero_steps():
         assert a.key == 0xFFFFFFFF
 
 
-def test_steps_left_count_is_a_safe_bound():
-    """kStepsLeft (csrc/leap_common.hpp): after a refresh, every one of the next `left` positions -- the reference's
+@pytest.mark.parametrize("short", [2, 0])
+def test_steps_left_count_is_a_safe_bound(short):
+    """(short = 0: the count of HMRM_CROSS builds, as tight as the estimate allows.)  kStepsLeft (csrc/leap_common.hpp): after a refresh, every one of the next `left` positions -- the reference's
     sequential p += s -- equals p + j * delta bit for bit, stays inside the binade and off its boundary; so a jump of
     n <= left steps needs no test at its landing point.  Random and adversarial starts (close to either boundary, exact
     ties, reciprocal errors of either sign at the measured 2^-24); brute force against sequential stepping."""
@@ -148,7 +150,7 @@ def test_steps_left_count_is_a_safe_bound():
         sign = rng.choice((1.0, -1.0))
         p, s = sign * p, sign * s
         a = L.Axis()
-        L.axis_refresh(a, p, s, rcp_err=rng.choice((0.0, 2.0 ** -24, -2.0 ** -24, rng.uniform(-1, 1) * 2.0 ** -24)))
+        L.axis_refresh(a, p, s, rcp_err=rng.choice((0.0, 2.0 ** -24, -2.0 ** -24, rng.uniform(-1, 1) * 2.0 ** -24)), short=short)
         if a.left < 0:
             continue
         q, key = p, L.hi32(p) >> 20
@@ -170,3 +172,41 @@ def test_steps_left_count_is_a_safe_bound():
         checked += 1
         long_runs += a.left > 3000
     assert checked > 3000 and long_runs > 100
+
+
+def test_jumps_ending_in_a_real_step_cross_binades_exactly():
+    """HMRM_CROSS (csrc/render_fast.hip): a jump is `left` multiplied steps and then one real step fl(p + s).  A ray
+    that only ever moves that way -- refresh, jump to the binade's end, cross with the real step, refresh ... -- visits
+    positions of the reference's sequence p += s, bit for bit, through many binades in either direction; and the
+    real step after the counted ones does leave the binade nearly always (else the next refresh fails and a group
+    of real steps is marched, as before)."""
+    rng = random.Random(11)
+    crossings = stuck = 0
+    for trial in range(300):
+        e = rng.randint(2, 9)
+        p = math.ldexp(1.0 + rng.random(), e) * rng.choice((1.0, -1.0))
+        s = math.ldexp(rng.random() + 0.05, e - rng.randint(5, 9)) * rng.choice((1.0, -1.0))
+        if trial % 5 == 0:
+            s = _tie_step(p, rng.randint(1, 2 ** 12), rng.choice((1.0, -1.0)))
+        q = p            # the reference's sequence
+        taken = 0
+        a = L.Axis()
+        while taken < 4000 and 2.0 ** -3 < abs(p) < 2.0 ** 12:
+            L.axis_refresh(a, p, s, rcp_err=rng.uniform(-1, 1) * 2.0 ** -24, short=0)
+            if a.left < 0:
+                # (not exact here: the kernel marches real steps; a group of 4)
+                n = 4
+                for _ in range(n):
+                    p = p + s
+                stuck += 1
+            else:
+                mult = min(a.left, 700)                 # (any count up to `left` is a valid jump)
+                n = mult + 1
+                key = L.hi32(p) >> 20
+                p = (p + float(mult) * a.delta) + s     # multiplied steps, then the real one
+                crossings += (L.hi32(p) >> 20) != key
+            for _ in range(n):
+                q = q + s
+            taken += n
+            assert bits(p) == bits(q), (trial, taken)
+    assert crossings > 500 and stuck < crossings // 2

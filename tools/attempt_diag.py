@@ -1,4 +1,4 @@
-"""Why leap attempts fail and at which pyramid level (instrumented kernel, HMRM_DIAG_ITERS=4..11)."""
+"""Why leap attempts fail and at which pyramid level (instrumented kernel, HMRM_DIAG_ITERS=4..20)."""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 hm = importlib.import_module("heightmap-ray-marcher_amd")
@@ -27,7 +27,8 @@ for name in sys.argv[1:] or ["C3", "C5"]:
                          (12, ("wave iterations", "with attempt block", "with group block", "active lanes")),
                          (13, ("attempt lane slots", "attempt useful", "group lane slots", "group useful")),
                          (14, ("attempt iters share<1/8", "1/8..1/4", "1/4..1/2", ">=1/2")),
-                         (15, ("group iters share<1/8", "1/8..1/4", "1/4..1/2", ">=1/2"))):
+                         (15, ("group iters share<1/8", "1/8..1/4", "1/4..1/2", ">=1/2")),
+                         (20, ("groups after a jump to a binade's end", "after an attempt without binade room", "without an attempt", "after other attempts"))):
         os.environ["HMRM_DIAG_ITERS"] = str(mode)
         cam.bg_r = mode  # defeat the frame cache
         _, s2, *_ = scene.render_stats(cam)
