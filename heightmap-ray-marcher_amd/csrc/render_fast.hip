@@ -282,10 +282,13 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						if (__ballot(inb0 && exact && above) != 0ull) {
 							// estimates of the steps left before each constraint bites; rdel is signed like
 							// the motion, so every quotient is >= 0.  Only estimates: verified below.
+							// (a coordinate that does not move -- s == 0 or absorbed -- has rdel = 2^40 and is strictly inside
+							// of whichever edge it looks at: a huge quotient once its sign is dropped, which costs nothing -- an
+							// operand modifier -- and changes nothing for a moving coordinate.  No case distinction needed.)
 							const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;  // x edge ahead
 							const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid; // y edge ahead
 							if (kStepsLeft) {
-								room = sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40;
+								room = __builtin_fabs((ex - x) * ax.rdel);
 							} else {
 								room = (ax.lim - x) * ax.rdel;
 								room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 								room_b = room; // steps left inside the three binades
 								room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
 							}
-							room = __builtin_fmin(room, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
+							room = __builtin_fmin(room, kStepsLeft ? __builtin_fabs((ey - y) * ay.rdel) : (sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40));
 							room_z = sz < 0.0 ? (m - z) * az.rdel : 0x1p40;
 							z_bound = room_z < room;
 							room = __builtin_fmin(room, room_z);
