@@ -59,6 +59,7 @@ struct Knobs {
 	int order_mode = 2;                  // HMRM_TILE_ORDER=1 -> plain rotation; 2 (default) -> rotation, then calibrated from measurement
 	int diag_mode = 0;                   // HMRM_DIAG_ITERS (tools)
 	int min_level = -1;                  // HMRM_MIN_LEVEL (tools)
+	int finest_pause = -1;               // HMRM_FINEST_PAUSE (tools)
 	bool order_verbose = false;          // HMRM_ORDER_VERBOSE=1 (tools): report every calibration on stderr
 	int seg_n = 0;                       // HMRM_TILE_SEGMENTS=b0:c0,b1:c1,.. (tools): tile-row pieces to start first, in this order
 	int seg_b[3] = {0, 0, 0}, seg_c[3] = {0, 0, 0};
@@ -93,6 +94,8 @@ Knobs read_knobs() {
 	}
 	if (const char *s = getenv("HMRM_MIN_LEVEL"))
 		if (s[0] >= '0' && s[0] < '0' + hmrm::kMipLevels) k.min_level = s[0] - '0';
+	if (const char *s = getenv("HMRM_FINEST_PAUSE"))
+		if (s[0] >= '0' && s[0] <= '9') k.finest_pause = s[0] - '0';
 	return k;
 }
 
@@ -448,6 +451,7 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 	f->step_cap = s->knobs.step_cap;
 	f->diag_mode = s->knobs.diag_mode;
 	if (s->knobs.min_level >= 0) f->min_level = s->knobs.min_level;
+	if (s->knobs.finest_pause >= 0) f->finest_pause = s->knobs.finest_pause;
 	if (slot_out) *slot_out = slot;
 	return HMRM_OK;
 }

@@ -171,11 +171,12 @@ void build_frame(const HostCamera &cam, int32_t map_w, int32_t map_h, double min
 	// cell that is too few steps for a jump to pay for its bookkeeping, and the 16-cell level is
 	// the finest one used (measured: C3 at 0.25 cells/step wants the 4-cell level, C2/C4/C5 at 0.5
 	// run 5-7 % faster without it).  After a refused attempt at the finest level the ray marches
-	// real steps before it looks again: one group when windows are 4 cells (16 steps) wide, four
-	// when they are 16 cells (32 steps) wide (2-4 % either way).
+	// real steps before it looks again: one group when windows are 4 cells (16 steps) wide, seven
+	// when they are 16 cells (32 steps) wide (tools/min_level_exp.py, round 3: a pause of 6 extra groups
+	// against 3 is C5 -1.9 %, C2 -1.1 %, C4 -0.4 %; 8 the same).
 	const double cells_per_step = std::fabs(cam.step_dist / grid_width);
 	f->min_window = cells_per_step > 0.35 ? 16 : 4;
-	f->finest_pause = cells_per_step > 0.35 ? 3 : 0;
+	f->finest_pause = cells_per_step > 0.35 ? 6 : 0;
 	f->min_level = 0; // (api.cpp turns min_window into a level of the pyramid it built)
 }
 

@@ -20,6 +20,18 @@ for name in sys.argv[1:] or ["C3", "C5", "C2", "C4"]:
                 os.environ.pop("HMRM_MIN_LEVEL", None)
             os.environ["HMRM_TILE_ORDER"] = "1"   # (plain rotation: no calibration noise between the variants)
             times[l].append(scene.bench_kernel_ms(cam, 10))
-    _, st, _, _ = scene.render_stats(cam)
     print(name, " ".join(f"[{l or 'default'}] {np.median(times[l][1:]):.4f}" for l in levels), flush=True)
+    os.environ.pop("HMRM_MIN_LEVEL", None)
+    # the pause (groups marched before the next attempt) after a failed height test at the finest level: HMRM_FINEST_PAUSE
+    pauses = ["", "0", "1", "3", "6", "8"]
+    times = {l: [] for l in pauses}
+    for rnd in range(6):
+        for l in pauses:
+            if l:
+                os.environ["HMRM_FINEST_PAUSE"] = l
+            else:
+                os.environ.pop("HMRM_FINEST_PAUSE", None)
+            times[l].append(scene.bench_kernel_ms(cam, 10))
+    os.environ.pop("HMRM_FINEST_PAUSE", None)
+    print(name, "pause", " ".join(f"[{l or 'default'}] {np.median(times[l][1:]):.4f}" for l in pauses), flush=True)
     scene.close()
