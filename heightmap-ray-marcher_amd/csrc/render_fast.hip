@@ -79,6 +79,13 @@ constexpr double kUpRatio = HMRM_UP_RATIO; // see the level policy in k_render_f
 constexpr int kAdaptAfter = (kLevelStep == 1) ? HMRM_ADAPT_AFTER : 0;
 constexpr bool kAdaptive = kAdaptAfter > 0;
 
+// HMRM_EARLY_LOAD (default 1): order of an attempt -- the pyramid look-up is issued first, refreshes and lateral estimates
+// run while it is in flight (see the attempt block).  0 = refresh first and estimates after the load, for A/B runs.
+#ifndef HMRM_EARLY_LOAD
+#define HMRM_EARLY_LOAD 1
+#endif
+constexpr bool kEarlyLoad = HMRM_EARLY_LOAD != 0;
+
 // ---- bilinear quality mode (HMRM_BILINEAR; a build-side addition, not in the reference) ----
 // Same definition, operation for operation, as oracle/hmrm_oracle.c "bilinear quality mode":
 // values sit at cell centres; u = q - 0.5, t = u - floor(u), neighbours clamp(floor(u)) and
@@ -236,21 +243,26 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 					cooldown -= attempt ? 0 : 1;
 					if (attempt) {
 						diag.on_attempt();
-						const bool stale_x = kStepsLeft ? ax.left < 0 : (hi32(x) >> 20) != ax.key;
-						const bool stale_y = kStepsLeft ? ay.left < 0 : (hi32(y) >> 20) != ay.key;
-						const bool stale_z = kStepsLeft ? az.left < 0 : (hi32(z) >> 20) != az.key;
-						diag.on_refresh_check(f, stale_x, stale_y, stale_z);
-						if (stale_x) axis_refresh(ax, x, sx);
-						if (stale_y) axis_refresh(ay, y, sy);
-						if (stale_z) axis_refresh(az, z, sz);
+						// Order of the block (HMRM_EARLY_LOAD): the window look-up depends on the position and the level only, so
+						// its load is issued FIRST; the refreshes of stale coordinates and the estimates of lateral room, which
+						// do not need the loaded maximum, then run while it is in flight.  For a wave alone on its SIMD -- the
+						// long waves at the end of a launch -- a trip is one chain of dependent instructions, and this takes
+						// the refreshes and ~20 instructions of the estimate out of the part that waits for the load.
+						auto refresh_stale = [&]() {
+							const bool stale_x = kStepsLeft ? ax.left < 0 : (hi32(x) >> 20) != ax.key;
+							const bool stale_y = kStepsLeft ? ay.left < 0 : (hi32(y) >> 20) != ay.key;
+							const bool stale_z = kStepsLeft ? az.left < 0 : (hi32(z) >> 20) != az.key;
+							diag.on_refresh_check(f, stale_x, stale_y, stale_z);
+							if (stale_x) axis_refresh(ax, x, sx);
+							if (stale_y) axis_refresh(ay, y, sy);
+							if (stale_z) axis_refresh(az, z, sz);
+						};
+						if (!kEarlyLoad) refresh_stale();
 						bool near0 = false;
 						double qx = cell_coord_fast<GWM>(x, f, near0), qy = cell_coord_fast<GWM>(-y, f, near0);
 						if (GWM == 2 && near0) { qx = x / f.grid_width; qy = -y / f.grid_width; }
 						const int gx = cvt_i32_sat(qx), gy = GWM == 0 ? cvt_i32_sat_neg(y) : cvt_i32_sat(qy);
 						const bool inb0 = (unsigned)gx < wlim && (unsigned)gy < hlim;
-						const bool exact = kStepsLeft ? (ax.left | ay.left | az.left) >= 0
-						                              : ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
-						const int left_min = min(ax.left, min(ay.left, az.left)); // (kStepsLeft)
 						const bool top = lev == kTopLevel;
 						// window (ix,iy) of level lev: S = 4 << lev cells wide, one every 1<<hs cells.  The whole map is
 						// the one window of the top plane: with hs = 28 every in-grid cell has ix = iy = 0 and the
@@ -267,11 +279,29 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						// (a 32-bit byte offset from the pyramid's base: at most 8 planes of 2^27 floats, api.cpp's map limit)
 						float mf = *(const float *)((const char *)mip + (size_t)((inb0 ? widx : 0u) * 4u));
 						diag.load_end(f, 17, mf);
-						const double m = (double)mf; // (floats rounded up: also bounds every float / interpolated threshold)
+						if (kEarlyLoad) refresh_stale();
+						const bool exact = kStepsLeft ? (ax.left | ay.left | az.left) >= 0
+						                              : ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
+						const int left_min = min(ax.left, min(ay.left, az.left)); // (kStepsLeft)
 						const int wx0 = ix << hs, wy0 = iy << hs;
 						// (the last windows of a row / column hang over the map's edge: the usable span ends at the edge)
 						const int wcells = top ? (1 << 30) : (4 << (kLevelStep * lev)); // window size S in cells
 						const int wspan_x = min(wcells, f.map_w - wx0), wspan_y = min(wcells, f.map_h - wy0);
+						// estimates of the steps left before each lateral constraint bites; rdel is signed like
+						// the motion, so every quotient is >= 0.  Only estimates: verified below.
+						// (a coordinate that does not move -- s == 0 or absorbed -- has rdel = 2^40 and is strictly inside
+						// of whichever edge it looks at: a huge quotient once its sign is dropped, which costs nothing -- an
+						// operand modifier -- and changes nothing for a moving coordinate.  No case distinction needed.)
+						const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;  // x edge ahead
+						const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid; // y edge ahead
+						double room_lat = 0.0;
+						if (kStepsLeft) {
+							room_lat = __builtin_fmin(__builtin_fabs((ex - x) * ax.rdel), __builtin_fabs((ey - y) * ay.rdel));
+							// (computed here, not sunk behind the wait for the load: the empty statement reads the estimate
+							// and stands between the load and the first use of its result)
+							if (kEarlyLoad) asm volatile("" : "+v"(mf) : "v"(room_lat));
+						}
+						const double m = (double)mf; // (floats rounded up: also bounds every float / interpolated threshold)
 						const bool above = z >= m;
 						// Nothing below can succeed unless the ray is above this window's maximum: when no
 						// lane of the wave is, skip the estimate and the verification (the usual case in
@@ -279,24 +309,18 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 						double room = 0.0, room_b = 0x1p40, room_z = 0.0;
 						bool z_bound = false, ok = false, can = false, binade_bound = false;
 						int n = 0;
-						if (__ballot(inb0 && exact && above) != 0ull) {
-							// estimates of the steps left before each constraint bites; rdel is signed like
-							// the motion, so every quotient is >= 0.  Only estimates: verified below.
-							// (a coordinate that does not move -- s == 0 or absorbed -- has rdel = 2^40 and is strictly inside
-							// of whichever edge it looks at: a huge quotient once its sign is dropped, which costs nothing -- an
-							// operand modifier -- and changes nothing for a moving coordinate.  No case distinction needed.)
-							const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;  // x edge ahead
-							const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid; // y edge ahead
+						const bool cand = inb0 && exact && above;
+						if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
 							if (kStepsLeft) {
-								room = __builtin_fabs((ex - x) * ax.rdel);
+								room = room_lat;
 							} else {
 								room = (ax.lim - x) * ax.rdel;
 								room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
 								room = __builtin_fmin(room, (az.lim - z) * az.rdel);
 								room_b = room; // steps left inside the three binades
 								room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
+								room = __builtin_fmin(room, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
 							}
-							room = __builtin_fmin(room, kStepsLeft ? __builtin_fabs((ey - y) * ay.rdel) : (sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40));
 							room_z = sz < 0.0 ? (m - z) * az.rdel : 0x1p40;
 							z_bound = room_z < room;
 							room = __builtin_fmin(room, room_z);
@@ -312,7 +336,7 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 							} else {
 								binade_bound = room_b <= room;
 							}
-							can = inb0 && exact && above && n >= kMinLeap;
+							can = cand && n >= kMinLeap;
 							// landing point and its exact verification
 							// (kCross: n - 1 steps by multiplication, all inside the three binades by count, then one real step
 							// from that exact position.  Coordinates move monotonically, so the tests of the end point below
