@@ -385,6 +385,36 @@ def test_exact_tie_steps_and_many_binades(gpu, oracle):
     scene.close()
 
 
+def test_jumps_cross_binade_boundaries_themselves(gpu, oracle, monkeypatch):
+    """csrc/render_fast.hip (HMRM_CROSS): a jump ends with one real step, so a jump that a binade's end cut short
+    carries its coordinate into the next binade itself.  The instrumented kernel counts what came before each group of
+    real steps (diagnostic mode 20): none may follow such a jump any more -- before, half of all groups did.  Pixels and
+    step counts against the oracle as everywhere; a general grid width, whose binade boundaries fall inside windows."""
+    rng = np.random.RandomState(21)
+    mw = mh = 512
+    rgb = np.repeat(rng.randint(0, 30, size=(mh, mw, 1)).astype(np.uint8), 3, axis=2)
+    cmap = rng.randint(0, 256, size=(mh, mw, 4)).astype(np.uint8)
+    cmap[:, :, 3] = 255
+    for gw in (1.0, 0.3):
+        params = gpu.SceneParams.make(0.0, 12.0 * gw, grid_width=gw)
+        cam = gpu.Camera.make(width=96, height=64, projection=1, hfov=gpu.degrees_to_rads(70), hang=gpu.degrees_to_rads(40),
+                              vang=gpu.degrees_to_rads(100), pos=(30.0 * gw, -40.0 * gw, 60.0 * gw), step_dist=0.11 * gw, bg=(1, 2, 3))
+        scene = gpu.Scene(rgb, cmap, params)
+        heights = oracle.update_heightmap(rgb, params)
+        ofb, total, capped, osteps, _ = oracle.render(oracle.make_cfg(cam, params, mw, mh), heights, cmap, per_pixel=True)
+        fb, st, steps, _ = scene.render_stats(cam, per_pixel=True)
+        assert capped == 0 and np.array_equal(fb, ofb) and np.array_equal(steps.astype(np.int64), osteps)
+        assert st.leaps > 1000 and st.leaped_steps > 0.8 * st.steps
+        monkeypatch.setenv("HMRM_DIAG_ITERS", "20")
+        cam.bg_r = 7  # (another frame record: the diagnostic mode is not part of the cache key)
+        _, d, *_ = scene.render_stats(cam)
+        monkeypatch.delenv("HMRM_DIAG_ITERS")
+        after_binade_jump, no_binade_room, paused, other = d.leap_attempts, d.leaps, d.groups, d.leaped_steps
+        assert after_binade_jump == 0, (gw, after_binade_jump, no_binade_room, paused, other)
+        assert paused + other > 0
+        scene.close()
+
+
 @pytest.mark.parametrize("gw,sd", [(0.3, 0.15), (0.05, 0.02), (3.0, 0.7)])
 def test_general_grid_width_full_frame(gpu, oracle, gw, sd):
     """grid_width that is not a power of two: cell = trunc(x * fl(1/gw)) with the true division only
