@@ -67,10 +67,14 @@ if os.environ.get("HMRM_TIMELINE_NPZ"):
     np.savez_compressed(os.environ["HMRM_TIMELINE_NPZ"], start=start.astype(np.float32), end=end.astype(np.float32), row=wave_row0.astype(np.int32),
                         col=bx.astype(np.int32), steps=wsteps, trips=wtrips.astype(np.int32), xcc=xcc.astype(np.int8))
 print(f"{name} [{extra}]: {used} waves, {int((wsteps > 0).sum())} marching; launch span {T:.0f} ticks of s_memrealtime (100 MHz: {T / 100:.1f} us); launch order pieces: first {seg_first}, delta {seg_delta}")
-print("per-XCD: waves, marching waves, last finish (fraction of the span)")
+print("per-XCD: waves, marching waves, last finish (fraction of the span); then: when half / 90 % of its waves had started (t/T), "
+      "wave-time spent (us summed over waves), median us per trip of its marching waves with 8..32 trips")
 for x in np.unique(xcc):
     m = xcc == x
-    print(f"  xcc {int(x)}: {int(m.sum()):6d} {int((m & (wsteps > 0)).sum()):6d}  {end[m].max() / T:.3f}")
+    mid = m & (wtrips >= 8) & (wtrips < 32)
+    print(f"  xcc {int(x)}: {int(m.sum()):6d} {int((m & (wsteps > 0)).sum()):6d}  {end[m].max() / T:.3f}   started 50 % {np.percentile(start[m], 50) / T:.3f} "
+          f"90 % {np.percentile(start[m], 90) / T:.3f}   wave-time {(end[m] - start[m]).sum() / 100:9.0f} us   "
+          f"us/trip {np.median((end[mid] - start[mid]) / 100 / wtrips[mid]) if mid.any() else 0:.3f}")
 nb = 50
 print("bin   t/T  resident(all)  resident(marching)  median-frame-row(marching)  waves-started")
 for b in range(nb):
