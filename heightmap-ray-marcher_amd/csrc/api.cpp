@@ -60,7 +60,6 @@ struct Knobs {
 	int diag_mode = 0;                   // HMRM_DIAG_ITERS (tools)
 	int min_level = -1;                  // HMRM_MIN_LEVEL (tools)
 	int finest_pause = -1;               // HMRM_FINEST_PAUSE (tools)
-	bool sky_rows = true;                // HMRM_SKY_ROWS=0 (tools): spherical frames without the table of whole-row miss colours
 	bool order_verbose = false;          // HMRM_ORDER_VERBOSE=1 (tools): report every calibration on stderr
 	int seg_n = 0;                       // HMRM_TILE_SEGMENTS=b0:c0,b1:c1,.. (tools): tile-row pieces to start first, in this order
 	int seg_b[3] = {0, 0, 0}, seg_c[3] = {0, 0, 0};
@@ -95,7 +94,6 @@ Knobs read_knobs() {
 	}
 	if (const char *s = getenv("HMRM_MIN_LEVEL"))
 		if (s[0] >= '0' && s[0] < '0' + hmrm::kMipLevels) k.min_level = s[0] - '0';
-	if (const char *s = getenv("HMRM_SKY_ROWS")) k.sky_rows = s[0] != '0';
 	if (const char *s = getenv("HMRM_FINEST_PAUSE"))
 		if (s[0] >= '0' && s[0] <= '9') k.finest_pause = s[0] - '0';
 	return k;
@@ -342,7 +340,7 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 		double *cc = nullptr, *cs = nullptr, *rs = nullptr, *rc = nullptr;
 		const size_t W = (size_t)cam->width, H = (size_t)cam->height;
 		if (cam->projection == HMRM_SPHERICAL) {
-			const size_t n = 2 * W + 2 * H + (H + 1) / 2; // (tables, then H colour words: DevFrame::sky_rows)
+			const size_t n = 2 * W + 2 * H;
 			if (n > c->arena_n) {
 				// (kernels of this stream may still read the old tables; every cached spherical record of the context
 				// loses its tables with the old arena)
@@ -402,9 +400,7 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 		if (cam->projection == HMRM_SPHERICAL) {
 			// stream order puts the upload (a small kernel reading the pinned staging memory) behind every earlier
 			// kernel of this stream that read the slot's device tables and in front of the one about to be launched
-			HIP_TRY(hmrm::launch_upload_tables(c->h_arena_dev + (slot->h_tables - c->h_arena), slot->d_tables, 2 * W + 2 * H,
-			                                   (uint32_t *)(slot->d_tables + 2 * W + 2 * H), (int)H, 2 * W + H, fr, c->stream));
-			fr.sky_rows = 1;
+			HIP_TRY(hmrm::launch_upload_tables(c->h_arena_dev + (slot->h_tables - c->h_arena), slot->d_tables, 2 * W + 2 * H, c->stream));
 			HIP_TRY(hipEventRecord(slot->uploaded, c->stream));
 			fr.col_cos_ha = slot->d_tables;
 			fr.col_sin_ha = slot->d_tables + W;
@@ -456,7 +452,6 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 	f->diag_mode = s->knobs.diag_mode;
 	if (s->knobs.min_level >= 0) f->min_level = s->knobs.min_level;
 	if (s->knobs.finest_pause >= 0) f->finest_pause = s->knobs.finest_pause;
-	if (!s->knobs.sky_rows) f->sky_rows = 0;
 	if (slot_out) *slot_out = slot;
 	return HMRM_OK;
 }

@@ -152,10 +152,6 @@ __device__ __forceinline__ int slab_classify(const DevRay &r, const DevFrame &f,
 // distance() (AABB.cpp:49-77) ends in inf or in an entry distance <= hi < 0: a miss.
 // PROJ 1 / 2: the origin is the camera for every ray, so the two box-side tests are done once per frame on the
 // host (camera.cpp, DevFrame::box_side) and a ray only adds the sign and the exponent of its direction.
-// one axis of the test below for PROJ 1 / 2: hd = high word of the direction component, side = DevFrame::box_side[i]
-__device__ __forceinline__ bool dir_points_away(uint32_t hd, uint32_t side) {
-	return ((((hd >> 20) & 0x7ffu) - 523u) < 1000u) & (((side ^ hd) >> 31) != 0u);
-}
 template <int PROJ>
 __device__ __forceinline__ bool slab_points_away(const DevRay &r, const DevFrame &f) {
 	const double ro[3] = {r.px, r.py, r.pz};
@@ -166,7 +162,7 @@ __device__ __forceinline__ bool slab_points_away(const DevRay &r, const DevFrame
 		for (int i = 0; i < 3; ++i) {
 			if (!f.box_side_known[i]) continue; // (uniform)
 			const uint32_t hd = (uint32_t)((unsigned long long)__double_as_longlong(rd[i]) >> 32);
-			away = away | dir_points_away(hd, f.box_side[i]);
+			away = away | ((((hd >> 20) & 0x7ffu) - 523u) < 1000u & ((f.box_side[i] ^ hd) >> 31) != 0u);
 		}
 		return away;
 	}
@@ -208,18 +204,15 @@ struct StatsOut {
 
 
 // Miss shade: hmap.cpp:1041-1057.
-__device__ __forceinline__ uint32_t shade_miss_bg(uint32_t bg_r, uint32_t bg_g, uint32_t bg_b, double dz) {
+__device__ __forceinline__ uint32_t shade_miss(const DevFrame &f, double dz) {
 	if (dz > 0.0) {
 		const double zz = dz * dz; // std::pow(z,2) == z*z under -std=c++98 (__builtin_powi)
-		const double r_ = 220.0 * zz + (double)bg_r;
-		const double g_ = 240.0 * zz + (double)bg_g;
-		const double b_ = 255.0 * dz + (double)bg_b;
+		const double r_ = 220.0 * zz + (double)f.bg[0];
+		const double g_ = 240.0 * zz + (double)f.bg[1];
+		const double b_ = 255.0 * dz + (double)f.bg[2];
 		return pack_rgba(sky_channel(r_), sky_channel(g_), sky_channel(b_));
 	}
-	return pack_rgba(bg_r, bg_g, bg_b);
-}
-__device__ __forceinline__ uint32_t shade_miss(const DevFrame &f, double dz) {
-	return shade_miss_bg(f.bg[0], f.bg[1], f.bg[2], dz);
+	return pack_rgba(f.bg[0], f.bg[1], f.bg[2]);
 }
 
 // Hit shade: hmap.cpp:1018-1031 (alpha 0 -> background colour).

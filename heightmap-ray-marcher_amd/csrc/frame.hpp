@@ -64,9 +64,7 @@ struct DevFrame {
 	int32_t min_level;           // finest pyramid level worth an attempt (api.cpp, from min_window)
 	int32_t min_window;          // ... as a window size in cells (camera.cpp)
 	int32_t finest_pause;        // extra groups marched after a refused attempt at that level (camera.cpp)
-	int32_t sky_rows;            // spherical only: 1 = a table of H colours follows row_cos_va's H doubles -- for every row whose rays
-	                             // all miss by the z test of slab_points_away alone (direction and miss colour depend on the row only)
-	                             // the colour shade_miss gives it, else 0 (render.hip k_upload_tables fills it; api.cpp)
+	int32_t pad4_;
 };
 
 // Window sizes S = 4 * 2^(kLevelStep*l) cells, placed every S/2 cells.  kLevelStep 1 (the build): S = 4, 8, 16, 32,

@@ -247,27 +247,14 @@ hipError_t launch_rcp_error(int mode, uint64_t count, uint64_t seed, int exp_lo,
 // Spherical tables, pinned host staging -> device, by a kernel of the launch stream instead of a copy command: a
 // DMA copy between two kernels of one stream costs two cross-engine hand-overs (~25 us per frame measured on a
 // moving camera); this is one more small dispatch on the same queue, reading 96 KB (4K frame) over PCIe.
-__global__ __launch_bounds__(256) void k_upload_tables(const double *__restrict__ host_src, double *__restrict__ dst, int n,
-                                                       uint32_t *__restrict__ sky, int sky_rows, int row_cos_at,
-                                                       uint32_t bg_r, uint32_t bg_g, uint32_t bg_b, uint32_t side_z, int side_z_known) {
+__global__ __launch_bounds__(256) void k_upload_tables(const double *__restrict__ host_src, double *__restrict__ dst, int n) {
 	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (i < n) dst[i] = host_src[i];
-	// DevFrame::sky_rows: a spherical ray's z component is its row's cos(va), and so is everything its miss colour
-	// depends on.  A row whose direction passes the z axis' test of slab_points_away -- the test every pixel of it would
-	// pass in the march kernel -- misses as a whole: the march kernel stores this colour and does nothing else there.
-	if (i < sky_rows) {
-		const double cva = host_src[row_cos_at + i];
-		const uint32_t hd = (uint32_t)((unsigned long long)__double_as_longlong(cva) >> 32);
-		sky[i] = (side_z_known && dir_points_away(hd, side_z)) ? shade_miss_bg(bg_r, bg_g, bg_b, cva) : 0u; // (alpha 255: never 0)
-	}
 }
 
-hipError_t launch_upload_tables(const double *h_pinned, double *d_dst, size_t n, uint32_t *d_sky, int sky_rows, size_t row_cos_at,
-                                const DevFrame &f, hipStream_t stream) {
+hipError_t launch_upload_tables(const double *h_pinned, double *d_dst, size_t n, hipStream_t stream) {
 	if (n == 0 || n > 0x7fffffffu) return n ? hipErrorInvalidValue : hipSuccess;
-	hipLaunchKernelGGL(k_upload_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, h_pinned, d_dst, (int)n, d_sky,
-	                   d_sky ? sky_rows : 0, (int)row_cos_at, (uint32_t)f.bg[0], (uint32_t)f.bg[1], (uint32_t)f.bg[2], f.box_side[2],
-	                   (int)f.box_side_known[2]);
+	hipLaunchKernelGGL(k_upload_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, h_pinned, d_dst, (int)n);
 	return hipGetLastError();
 }
 

@@ -56,9 +56,7 @@ hipError_t launch_measure_init(unsigned long long *d_rec, int tile_rows, hipStre
 hipError_t launch_measure_readback(const unsigned long long *d_rec, unsigned long long *h_pinned_dev, int tile_rows, hipStream_t stream);
 
 // n doubles from pinned (device-mapped) host memory into device memory, as a kernel on `stream` (render.hip).
-// (+ the table of whole-row miss colours, DevFrame::sky_rows: d_sky = H words behind the tables, or null)
-hipError_t launch_upload_tables(const double *h_pinned, double *d_dst, size_t n, uint32_t *d_sky, int sky_rows, size_t row_cos_at,
-                                const DevFrame &f, hipStream_t stream);
+hipError_t launch_upload_tables(const double *h_pinned, double *d_dst, size_t n, hipStream_t stream);
 
 // v_rcp_f64 accuracy probe (render.hip k_rcp_error): d_out65[0] = max relative error as fp64 bits, [1..64] = histogram
 // by binary order of magnitude; the caller zeroes d_out65.

@@ -173,21 +173,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 	unsigned long long my_steps = 0;
 	uint32_t my_hit = 0, my_cap = 0;
 
-	// Spherical frames: rows whose rays all miss (DevFrame::sky_rows: decided and shaded once per camera by
-	// k_upload_tables, with the z test and the shade this kernel would apply to each of their pixels) cost one look-up
-	// and the store.  Not in the instrumented variant, which reports every ray's distance.
-	// (The look-up is issued together with the ray's table loads -- one wait for all of them: the empty statement
-	// keeps the compiler from moving the ray behind the test, which would make every other wave wait twice.)
-	uint32_t sky = 0u;
-	DevRay ray; // (read only where pid.live: left uninitialised on purpose, zeroing it costs every wave six moves)
 	if (pid.live) {
-		if (PROJ == 2 && !STATS && f.sky_rows != 0) sky = reinterpret_cast<const uint32_t *>(f.row_cos_va + f.screen_h)[pid.py];
-		ray = make_ray<PROJ>(f, pid.px, pid.py);
-		if (PROJ == 2 && !STATS) asm volatile("" : "+v"(sky) : "v"(ray.dx), "v"(ray.dy), "v"(ray.dz));
-	}
-	if (sky != 0u) out[(uint64_t)(uint32_t)pid.lrow * (uint32_t)out_stride_px + (uint32_t)pid.px] = sky;
-
-	if (pid.live && sky == 0u) {
+		const DevRay ray = make_ray<PROJ>(f, pid.px, pid.py);
 		// most rays of a frame never touch the box: prove the miss cheaply where possible (the instrumented
 		// variant reports d, so it takes no shortcut for misses); most of the others get their entry distance
 		// from one division instead of six (slab_classify: the instrumented variant uses that path too, so the

@@ -1105,44 +1105,6 @@ def test_bilinear_full_size_c3_subsampled(gpu, oracle):
     scene.close()
 
 
-def test_whole_sky_rows_of_a_spherical_frame(gpu, oracle, monkeypatch):
-    """DevFrame::sky_rows (csrc/render.hip k_upload_tables, render_fast.hip prologue): a spherical ray's z component
-    and its miss colour depend on its row alone, so rows whose direction passes the z test of the cheap miss proof are
-    shaded once per camera and the march kernel only stores that colour.  Frames with the table (default) and without
-    (HMRM_SKY_ROWS=0) against the oracle: camera above the box (upper rows are sky), below it (lower rows), inside its
-    height range (no row qualifies), looking straight up (all of them do), other background colours, a row strip,
-    and a second camera on the same stream (the table lives in the cached record)."""
-    import torch
-    rgb, cmap = scenes.small_maps(96, 80, 77)
-    params = gpu.SceneParams.make(2.0, 14.0, grid_width=1.0)
-    heights = oracle.update_heightmap(rgb, params)
-    scene = gpu.Scene(rgb, cmap, params)
-    sky_rows_seen = 0
-    for k, (pz, vang, bg) in enumerate(((40.0, 92.0, (1, 2, 3)), (40.0, 20.0, (200, 100, 50)), (-30.0, 60.0, (9, 9, 9)),
-                                        (8.0, 90.0, (0, 0, 0)), (40.0, 1.0, (250, 251, 252)), (14.5, 100.0, (30, 60, 90)))):
-        cam = gpu.Camera.make(width=150, height=117, projection=2, hfov=gpu.degrees_to_rads(170), hang=gpu.degrees_to_rads(25 * k),
-                              vang=gpu.degrees_to_rads(vang), pos=(40.0, -35.0, pz), step_dist=0.3, bg=bg)
-        ofb, total, capped, *_ = oracle.render(oracle.make_cfg(cam, params, 96, 80), heights, cmap)
-        assert capped == 0
-        with_table = scene.render(cam)
-        monkeypatch.setenv("HMRM_SKY_ROWS", "0")
-        without = scene.render(cam)
-        monkeypatch.delenv("HMRM_SKY_ROWS")
-        assert np.array_equal(with_table, ofb), k
-        assert np.array_equal(without, ofb), k
-        fbs, st, *_ = scene.render_stats(cam)
-        assert np.array_equal(fbs, ofb) and st.steps == total
-        buf = torch.zeros((60, cam.width, 4), dtype=torch.uint8, device="cuda")
-        scene.render_rows_device(cam, buf.data_ptr(), cam.width * 4, 30, 90, stream=torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        assert np.array_equal(buf.cpu().numpy(), ofb[30:90]), k
-        # rows of one colour that differ from the background exist when the camera sees sky above the horizon
-        uniform = [(ofb[r] == ofb[r, 0]).all() for r in range(cam.height)]
-        sky_rows_seen += sum(uniform)
-    assert sky_rows_seen > 100
-    scene.close()
-
-
 def test_launch_order_never_changes_a_pixel(gpu, oracle):
     """The cost-rotated launch order (api.cpp choose_tile_rot) is scheduling only: HMRM_TILE_ORDER=0
     (row-major) and the default order give identical frames, counters and strips; checked where the
