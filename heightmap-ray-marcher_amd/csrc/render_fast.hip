@@ -135,8 +135,9 @@ __device__ __forceinline__ uint32_t shade_hit_bilinear(const DevFrame &f, const 
 } // namespace
 
 // Tool build only (-DHMRM_TIMELINE, tools/timeline.py): every wave of the production (non-instrumented) kernel
-// stores its start and end time (s_memtime) and the XCD it ran on into pinned host memory; the library writes
-// the last launch's records to $HMRM_TIMELINE_FILE when the process ends.  Not compiled into the product.
+// stores its start and end time (s_memrealtime) and the XCD it ran on into a device buffer (not pinned host memory:
+// 129 600 records per 0.1 ms launch were 24 GB/s of PCIe writes, which disturbed what they measured); the library
+// copies the last launch's records out to $HMRM_TIMELINE_FILE when the process ends.  Not compiled into the product.
 #ifdef HMRM_TIMELINE
 struct TimelineRec { unsigned long long t0, t1; unsigned int xcc, pad; };
 __device__ TimelineRec *g_timeline = nullptr;
@@ -762,26 +763,27 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 	StatsOut st{d_counters, d_steps, d_entry};
 #ifdef HMRM_TIMELINE
 	{
-		static TimelineRec *host = nullptr;
+		static TimelineRec *host = nullptr, *devbuf = nullptr;
 		static size_t cap = 0, used = 0;
 		static int gx = 0, gy = 0, ty = 0, segs[7] = {0, 0, 0, 0, 0, 0, 0};
 		const size_t waves = (size_t)grid.x * grid.y * grid.z * (kBlockThreads / 64);
 		if (!stats) {
 			if (waves > cap) {
 				(void)hipDeviceSynchronize();
-				if (host) (void)hipHostFree(host);
-				(void)hipHostMalloc((void **)&host, waves * sizeof(TimelineRec), hipHostMallocMapped);
+				free(host);
+				if (devbuf) (void)hipFree(devbuf);
+				host = (TimelineRec *)malloc(waves * sizeof(TimelineRec));
+				(void)hipMalloc((void **)&devbuf, waves * sizeof(TimelineRec));
 				cap = waves;
-				TimelineRec *dev = nullptr;
-				(void)hipHostGetDevicePointer((void **)&dev, host, 0);
-				(void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &dev, sizeof dev);
+				(void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &devbuf, sizeof devbuf);
 				static bool registered = false;
 				if (!registered) {
 					registered = true;
 					atexit([] {
 						const char *path = getenv("HMRM_TIMELINE_FILE");
-						if (!path || !host) return;
+						if (!path || !host || !devbuf) return;
 						(void)hipDeviceSynchronize();
+						if (hipMemcpy(host, devbuf, used * sizeof(TimelineRec), hipMemcpyDeviceToHost) != hipSuccess) return;
 						if (FILE *fp = fopen(path, "wb")) {
 							const int hdr[12] = {gx, gy, kBlockThreads / 64, (int)used, ty, segs[0], segs[1], segs[2], segs[3], segs[4], segs[5], segs[6]};
 							fwrite(hdr, sizeof hdr, 1, fp);

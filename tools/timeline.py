@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Occupancy timeline of ONE launch of the PRODUCTION kernel (tool build -DHMRM_TIMELINE: every wave stores its start /
-end time and its XCD): waves resident per 1/50th of the launch, split into waves that march and waves that only shade a
+end time and its XCD, into a device buffer): waves resident per 1/50th of the launch, split into waves that march and waves that only shade a
 miss, the frame rows being worked on, per-XCD finish times.  Shows ramp, steady state and tail.
 usage (GPU box): python tools/timeline.py [workload] [extra -D flags]   (rebuilds the library twice)"""
 import importlib, os, struct, subprocess, sys
