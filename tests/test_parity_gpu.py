@@ -884,20 +884,21 @@ def test_c4_eight_rank_band_emulation_full_size(gpu, oracle):
 
 @pytest.mark.parametrize("script,args", [("deep_fuzz.py", ["20260000", "1000000", "150"]),
                                          ("deep_fuzz_big.py", ["20260000", "1000000", "150", "4096"]),
-                                         ("deep_fuzz_edges.py", ["20260000", "1000000", "100"])])
+                                         ("deep_fuzz_edges.py", ["20260000", "1000000", "100"]),
+                                         ("deep_fuzz_binades.py", ["20260000", "1000000", "60"])])
 def test_deep_fuzz_slice(gpu, script, args):
     """A seeded time-boxed slice of each long fuzzer (tests/deep_fuzz*.py: random maps from 1x1 up, random cameras
-    over the 4096^2 map, and cameras whose rays graze the box's edges and corners; all projections and sampling
-    modes, GPU vs oracle on frames, per-ray step counts, distance() bits and cap counts) inside the suite the
-    driver runs."""
+    over the 4096^2 map, cameras whose rays graze the box's edges and corners, and long low maps crossed end to end by
+    shallow rays through a dozen binades; all projections and sampling modes, GPU vs oracle on frames, per-ray step
+    counts, distance() bits and cap counts) inside the suite the driver runs."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, script)] + args, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0 and "mismatches 0" in r.stdout, tail
     import re
-    m = re.search(r"^scenes (\d+), mismatches 0|: cameras (\d+), mismatches 0", r.stdout, flags=re.M)
-    assert m and int(m.group(1) or m.group(2)) >= 150, tail
+    m = re.search(r"^scenes (\d+), mismatches 0|: cameras (\d+), mismatches 0|: scenes (\d+), mismatches 0", r.stdout, flags=re.M)
+    assert m and int(m.group(1) or m.group(2) or m.group(3)) >= 150, tail
     print(tail.strip().splitlines()[-1])  # (visible with -rP / in the junit output: how far the slice got)
 
 
