@@ -3,32 +3,51 @@
 
 A "step" is one pass of the hot path over one frame of synthetic input: the
 render kernel over every pixel of the workload's framebuffer.  Default workload
-= BASELINE.json configs[2], the configuration the metric is quoted on:
-3840x2160 over a 4096^2 heightmap, spherical hfov 180, step_dist 0.25 ("C3";
-`--workload C3h` is the north_star's step_dist 0.5 variant, C2/C5 also exist).
+at N = 1 = BASELINE.json configs[2], the configuration the metric is quoted on:
+3840x2160 over a 4096^2 heightmap, spherical hfov 180, step_dist 0.25 ("C3").
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3]
-  torchrun --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this process is only a LAUNCHER: before anything
+touches the GPU (torch is not even imported) it starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>` as a CHILD process,
+relays rank 0's one JSON line and exits with the child's code.  Launched under torch.distributed.run
+directly (WORLD_SIZE set: what the driver does) the same file is a rank.  `--dry-launch` runs launcher,
+rendezvous, sharding and the gather on CPU (gloo, a pattern instead of the renderer): the CPU test of
+the launch path (tests/test_bench_launch.py); its line says "dry_launch": true and carries no value.
 
 N = 1: `value` / `ms_per_step` = K frames of the workload's static pose launched BACK TO BACK ON ONE
        STREAM, maps resident in HBM, output to a device buffer -- the operating point `roofline`
        describes (`roofline.kernel_ms` = the same launches timed with HIP events on the launch stream).
+       Before the warm-up the pose is rendered 12 times with a synchronisation in between so that the
+       library's launch-order calibration has settled (`preconditioning`).
        Secondary blocks in the same line (never `value`):
-         frames_in_flight  the same K frames round-robin over 3 HIP streams (one launch's tail overlaps
-                           the next launch's start: a throughput mode for sequences of frames);
-         fresh_camera      a moving camera: every timed frame has a camera the library has never seen
-                           (orbit positions; host set-up -- libm calls, spherical sin/cos tables, upload --
-                           inside the timed loop), then the same cameras again out of the per-stream cache;
-                           for this workload and for C5 (perspective, same maps).
-N > 1: one process per GPU over RCCL, maps replicated.  `value` = frames of the workload's 64-frame
-       orbit, frame k on GPU k mod N (BASELINE config C5's sharding rule), K frames per GPU on one
+         value_moving_camera  ray-steps/s of `fresh_camera`'s timed frames: every frame a camera the
+                           library has never seen (host set-up inside the loop) -- what a moving
+                           camera gets; the headline's static pose is the best case;
+         frames_in_flight  the same K frames round-robin over 3 HIP streams;
+         fresh_camera      the moving-camera leg's timings (fresh, then the same cameras cached), also for C5;
+         workloads         the other BASELINE configurations on this GPU, each with kernel_ms (HIP
+                           events), ms_per_step (host clock, one stream), Mrays/s, reference-equivalent
+                           and executed steps: C3h (the north_star target: step_dist 0.5), C5 (static
+                           pose), C2, C4 (7680x4320 over 8192^2, the whole frame on one GPU);
+         literal_kernel    HMRM_KERNEL=simple on the headline frame: the kernel that executes every
+                           one of the reference's loads, with SURVEY 8(d)'s algorithmic-bytes fraction
+                           of the HBM peak (the figure that formula is defined for);
+         rough_terrain     the headline camera over maps built to defeat the traversal (white noise,
+                           a 255-spike per 256^2 block, needles on a plateau, a canyon flown at low
+                           altitude): production kernel against the plain 4-step groups.
+N > 1: one process per GPU over RCCL, maps replicated.  `value` = frames of BASELINE configs[4]'s
+       64-frame orbit ("C5"; `--workload` overrides), frame k on GPU k mod N, K frames per GPU on one
        stream each, no data-path collective, scaling "weak".  The same line carries `rccl_ranks`
-       (distinct (host, device) pairs seen by an all_gather: did RCCL really see N ranks) and the two
-       BASELINE multi-GPU configs as secondary blocks: `c5_frames` (C5's camera, same sharding) and
-       `c4_strips` (ONE 7680x4320 frame over the 8192^2 map in cyclic 16-row bands, twice: strips
-       gathered to rank 0 over RCCL, and every rank copying its strip to its own pinned host memory
-       over its own PCIe link, no collective).  `--mode strips` makes the gather variant of the
-       workload `value` instead (scaling "strong").
+       (distinct (host, device, bus) triples seen by an all_gather), `one_gpu_same_leg` (rank 0 alone
+       rendering K frames of the same orbit in the same run) with the speed-up and efficiency against
+       it, `static_pose_replicas` (the N = 1 line's own step on every GPU: comparable with that line's
+       `value`) and `c4_strips`: ONE 7680x4320 frame over the 8192^2 map (BASELINE configs[3]) in
+       cyclic 16-row bands, STRONG scaling -- kernel only, strips gathered to rank 0 over RCCL, every
+       rank copying its strip to its own pinned host memory (no collective) -- each with its time on
+       one GPU measured in the same run and the speed-up / efficiency against it.
+       `--mode strips` makes the gather variant of the workload `value` instead (scaling "strong").
 
 Rank 0 prints ONE JSON line.  value = REFERENCE-EQUIVALENT ray-steps/s: a ray-step is
 one execution of the reference's height load (main/hmap.cpp:1013-1014) and the count
@@ -36,7 +55,7 @@ is what the reference executes for the same frame (instrumented kernel variant,
 bit-identical pixels, run once, untimed; equal to the oracle's count).  The
 production kernel proves most of those loads unnecessary and skips them, so the
 line also says `"equivalent_steps": true` and carries the height samples and
-pyramid look-ups the kernel really executes.
+pyramid look-ups the kernel really executes; `mrays_per_s` is the algorithm-neutral rate.
 
 roofline: the kernel is bound by VALU issue, not by HBM, so
 `bound` = "valu-issue": achieved = VALU pipe-busy SIMD-cycles per second (PMC counts
@@ -52,10 +71,12 @@ cpu_baseline = the oracle (C port of the reference loop, OpenMP) timed on a boun
 row sample of the same frame on this host, median of 3 repetitions.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
 import socket
+import subprocess
 import sys
 import time
 
@@ -66,6 +87,133 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 SIMDS, PEAK_CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; max clock (MI355X_MICROARCH.md)
 BAND_ROWS = 16
 ORBIT_FRAMES = 64  # BASELINE config C5
+PRECONDITION_LAUNCHES = 12
+PROJ_NAMES = ("perspective", "spherical", "orthographic")
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default=None, help="default: C3 at N = 1, C5 (BASELINE configs[4]) at N > 1")
+    ap.add_argument("--mode", choices=["frames", "strips"], default="frames")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="streams the HEADLINE loop sends consecutive frames to (1 = back to back on one stream, the "
+                         "operating point of `roofline`; the 3-stream figure is always reported as a secondary block)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only: skip every secondary block")
+    ap.add_argument("--no-c4", action="store_true", help="skip the blocks that need the 8192^2 maps (workloads.C4, c4_strips)")
+    ap.add_argument("--no-rough", action="store_true", help="N = 1: skip the rough_terrain block")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="CPU rehearsal of the launch path: gloo instead of RCCL, a pattern instead of the renderer, no GPU touched")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks as a CHILD process (never an exec:
+    nothing in this process has touched the GPU, and nothing will), relay rank 0's JSON line, return its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this pool)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)  # (stderr passes through)
+    lines = [ln for ln in proc.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank job failed (exit code {proc.returncode}, "
+                         f"{len(lines)} JSON line(s) on its stdout)\n")
+        return proc.returncode or 1
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def _host_id():
+    return int.from_bytes(hashlib.sha256(socket.gethostname().encode()).digest()[:4], "little") & 0x7fffffff
+
+
+class Job:
+    """Rank, world and the timing harness of the contract: barrier + synchronize on both sides of the timed region,
+    maximum over ranks."""
+
+    def __init__(self, args, torch):
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dry = args.dry_launch
+        self.device = "cpu" if self.dry else "cuda"
+        # HMRM_FORCE_DIST=1 runs the torch.distributed (RCCL) code path even with one rank, so that
+        # the N>1 plumbing can be exercised on a single-GPU box
+        self.multi = self.world > 1 or os.environ.get("HMRM_FORCE_DIST", "") == "1"
+        self.dist = None
+        self.rccl_ranks = None
+
+    def init_dist(self):
+        torch = self.torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if self.dry:
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            me = torch.tensor([_host_id(), self.rank, 0], dtype=torch.int64)
+        else:
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device("cuda", self.local_rank))
+            # did RCCL see `world` ranks on `world` different GPUs?  Every rank contributes (a stable host id,
+            # device index, PCI bus id); the gathered rows are counted on rank 0.
+            props = torch.cuda.get_device_properties(self.local_rank)
+            bus = getattr(props, "pci_bus_id", self.local_rank)
+            dom = getattr(props, "pci_domain_id", 0)
+            me = torch.tensor([_host_id(), torch.cuda.current_device(), (int(dom) << 16 | int(bus)) & 0x7fffffff],
+                              dtype=torch.int64, device="cuda")
+        self.dist = dist
+        seen = [torch.zeros_like(me) for _ in range(self.world)]
+        dist.all_gather(seen, me)
+        self.rccl_ranks = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                           "distinct_devices": len({tuple(int(v) for v in t.tolist()) for t in seen})}
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def timed(self, step, n):
+        """n calls of step() bracketed by barrier + synchronize; max over ranks -> seconds."""
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def total(self, v):
+        if self.dist is None:
+            return int(v)
+        n = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.device)
+        self.dist.all_reduce(n, op=self.dist.ReduceOp.SUM)
+        return int(n.item())
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
 
 
 def _pmc_from_profiles(workload, src_sha):
@@ -86,7 +234,8 @@ def _pmc_from_profiles(workload, src_sha):
     if e.get("kernel_src_sha") != src_sha:
         prov["status"] = "stale: collected on other kernel sources; not used"
         return None, prov
-    prov["status"] = "ok: collected on these kernel sources (separate rocprofv3 --pmc passes, not this run)"
+    prov["status"] = ("ok: collected on these kernel sources (separate rocprofv3 --pmc passes on another box / run than this "
+                      "one's kernel_ms; boxes of the pool differ by +-3 %)")
     return e, prov
 
 
@@ -130,21 +279,88 @@ def cpu_baseline(hmrm, wl, rgb, cmap, params, cam, target_s=15.0, reps=3):
                       f"gcc -O2 -fopenmp -ffp-contract=off)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="C3")
-    ap.add_argument("--mode", choices=["frames", "strips"], default="frames")
-    ap.add_argument("--frames-in-flight", type=int, default=1,
-                    help="streams the HEADLINE loop sends consecutive frames to (1 = back to back on one stream, the "
-                         "operating point of `roofline`; the 3-stream figure is always reported as a secondary block)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip frames_in_flight / fresh_camera / c5_frames / c4_strips")
-    ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the c4_strips block (8192^2 maps)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
+def workload_text(wl):
+    return (f"{wl.name}: {wl.map_size}x{wl.map_size} heightmap, {wl.width}x{wl.height}, {PROJ_NAMES[wl.projection - 1]} "
+            f"hfov {wl.hfov_deg:g}, step_dist {wl.step_dist:g}, grid_width {wl.grid_width:g}"
+            + ("" if wl.content == "smooth" else f", {wl.content} map"))
+
+
+# ------------------------------------------------------------------------------------------ dry launch (CPU)
+def dry_main(args, job):
+    """The N > 1 control flow on CPU: gloo, a deterministic pattern instead of the renderer.  Exercises the launcher,
+    the rendezvous, the timing harness, the orbit sharding, the band plan and the gather; measures nothing."""
+    import numpy as np
+    torch = job.torch
+    strips = importlib.import_module("heightmap-ray-marcher_amd.strips")
+    if job.multi:
+        job.init_dist()
+    rank, world = job.rank, job.world
+    W, H = 64, 100
+
+    def pattern_rows(rows, frame=0):
+        r = np.asarray(rows, dtype=np.int64)[:, None, None]
+        x = np.arange(W, dtype=np.int64)[None, :, None]
+        c = np.arange(4, dtype=np.int64)[None, None, :]
+        return ((r * 131 + x * 7 + c * 3 + frame * 17) & 255).astype(np.uint8)
+
+    # frames: frame k on rank k mod world
+    mine = strips.orbit_frames_of_rank(rank, world, args.warmup + args.steps, ORBIT_FRAMES)
+    it = iter(mine)
+    rendered = []
+
+    def step_frames():
+        k = next(it)
+        rendered.append(int(pattern_rows(range(H), k).sum()))
+    for _ in range(args.warmup):
+        step_frames()
+    dt_frames = job.timed(step_frames, args.steps)
+    frames_total = job.total(args.steps)
+    # strips: cyclic bands + gather to rank 0
+    plan = strips.BandPlan(height=H, width=W, band_rows=BAND_ROWS, world=world)
+    strip = torch.zeros((plan.strip_rows, W, 4), dtype=torch.uint8)
+    block = torch.zeros((world, plan.strip_rows, W, 4), dtype=torch.uint8) if (rank == 0 and job.dist is not None) else None
+    out = {}
+
+    def render_rows(strip_t, band_rows, band_index, band_count):
+        rows = plan.rows_of(band_index)
+        host = strip_t.numpy()
+        host[:] = 0
+        k = 0
+        for b in plan.bands_of(band_index):
+            g0, g1 = b * band_rows, min((b + 1) * band_rows, H)
+            host[k * band_rows:k * band_rows + (g1 - g0)] = pattern_rows(range(g0, g1))
+            k += 1
+        assert len(rows) <= plan.strip_rows
+
+    def step_strips():
+        out["frame"] = strips.render_frame_distributed(plan, rank, render_rows, job.dist, strip, block)
+    dt_strips = job.timed(step_strips, max(1, min(args.steps, 3)))
+    ok = True
+    if rank == 0:
+        ok = bool(np.array_equal(out["frame"].numpy(), pattern_rows(range(H))))
+    bad = job.total(0 if ok else 1)
+    if rank == 0:
+        if bad:
+            raise SystemExit("bench.py --dry-launch: the gathered frame differs from the pattern")
+        line = {"metric": "ray-steps/s at 3840x2160, 4096^2 heightmap", "value": None, "unit": "ray-steps/s",
+                "dry_launch": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt_frames * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "dry launch: no renderer, no GPU (gloo rehearsal of the launch path)",
+                           "parallelism": f"frame k on rank k mod {world}; cyclic {BAND_ROWS}-row bands + gather to rank 0"},
+                "rccl_ranks": job.rccl_ranks, "frames_rendered_by_all_ranks": frames_total,
+                "strips_gather_ms": dt_strips * 1e3 / max(1, min(args.steps, 3))}
+        os.write(job.json_fd, (json.dumps(line) + "\n").encode())
+    job.finish()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ real ranks
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
 
     import numpy as np
     import torch
@@ -155,71 +371,39 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    job = Job(args, torch)
+    job.json_fd = json_fd
+    if job.world != args.gpus:
+        args.gpus = job.world  # (launched under torch.distributed.run with another --nproc-per-node: the environment wins)
+    if args.dry_launch:
+        return dry_main(args, job)
+    world, rank = job.world, job.rank
 
     hmrm = importlib.import_module("heightmap-ray-marcher_amd")
     strips = importlib.import_module("heightmap-ray-marcher_amd.strips")
-    if not torch.cuda.is_available() or hmrm.device_count() < 1:
+    n_dev = hmrm.device_count() if torch.cuda.is_available() else 0
+    if n_dev < 1:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    hmrm.set_device(local_rank)
-    dist = None
-    # HMRM_FORCE_DIST=1 runs the torch.distributed (RCCL) code path even with one rank, so that
-    # the N>1 plumbing can be exercised on a single-GPU box
-    force_dist = os.environ.get("HMRM_FORCE_DIST", "") == "1"
-    multi = world > 1 or force_dist
-    rccl_ranks = None
+    if job.local_rank >= n_dev:
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own (local rank {job.local_rank}, {n_dev} device(s) visible)")
+    torch.cuda.set_device(job.local_rank)
+    hmrm.set_device(job.local_rank)
+    multi = job.multi
     if multi:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-        # did RCCL see `world` ranks on `world` different GPUs?  Every rank contributes (host hash, device index,
-        # PCI bus id hash); the gathered rows are counted on rank 0.
-        props = torch.cuda.get_device_properties(local_rank)
-        bus = getattr(props, "pci_bus_id", local_rank)
-        me = torch.tensor([hash(socket.gethostname()) & 0x7fffffff, torch.cuda.current_device(), int(bus) & 0x7fffffff],
-                          dtype=torch.int64, device="cuda")
-        seen = [torch.zeros_like(me) for _ in range(world)]
-        dist.all_gather(seen, me)
-        rccl_ranks = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                      "distinct_devices": len({tuple(int(v) for v in t.tolist()) for t in seen})}
+        job.init_dist()
+    timed, total_over_ranks = job.timed, job.total
+    synth = hmrm.synth
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    wl_name = args.workload or ("C5" if (multi and args.mode == "frames") else "C3")
+    wl = synth.WORKLOADS[wl_name]
+    maps_cache = {}
 
-    def timed(step, n):
-        """n calls of step() bracketed by barrier + synchronize; max over ranks -> seconds."""
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
-
-    def total_over_ranks(v):
-        if dist is None:
-            return int(v)
-        n = torch.tensor([int(v)], dtype=torch.int64, device="cuda")
-        dist.all_reduce(n, op=dist.ReduceOp.SUM)
-        return int(n.item())
-
-    wl = hmrm.synth.WORKLOADS[args.workload]
-    rgb, cmap = hmrm.synth.synth_maps(wl.map_size)
+    def maps_of(w):
+        key = (w.map_size, w.content)
+        if key not in maps_cache:
+            maps_cache[key] = w.maps()
+        return maps_cache[key]
+    rgb, cmap = maps_of(wl)
     params, cam = wl.scene_params(), wl.camera()
     scene = hmrm.Scene(rgb, cmap, params)  # maps resident in HBM from here on
     W, H = cam.width, cam.height
@@ -245,11 +429,43 @@ def main():
             return lane
         return nxt, state
 
-    def orbit_leg(the_wl, the_scene, n_frames, n_warm, in_flight):
+    def precondition(the_scene, the_cam):
+        """Untimed: the library calibrates the launch order of a camera it sees repeatedly from a few measured launches
+        (csrc/launch_order.cpp; each needs the previous one finished, which a renderer that presents its frames does by
+        itself and a loop that queues hundreds of launches ahead does not): a dozen launches of the pose with a
+        synchronisation in between, then 50 more so that the GPU enters the timed region at steady clocks."""
+        for _ in range(PRECONDITION_LAUNCHES):
+            the_scene.bench_kernel_ms(the_cam, 1)
+        the_scene.bench_kernel_ms(the_cam, 50)
+
+    def static_leg(the_scene, the_cam, n_frames, n_warm, in_flight, ref_frame, active=True):
+        """n_frames launches of one pose on `in_flight` streams (1 = back to back), timed by the contract's harness.
+        Ranks with active=False take part in the barriers only.  -> seconds (max over ranks)."""
+        if not active:
+            return timed(lambda: None, n_frames)
+        keep, lanes = make_lanes(in_flight, the_cam.width, the_cam.height)
+        nxt, _ = round_robin(lanes)
+
+        def step():
+            st_, o_ = nxt()
+            the_scene.render_rows_device(the_cam, o_.data_ptr(), the_cam.width * 4, 0, the_cam.height, stream=st_)
+        for _ in range(n_warm):
+            step()
+        dt = timed(step, n_frames)
+        for st_, o_ in lanes[:min(in_flight, n_warm + n_frames)]:
+            if not np.array_equal(o_.cpu().numpy(), ref_frame):
+                raise SystemExit("bench.py: a timed static-pose leg produced a different frame than hmrm_render_stats")
+        del keep
+        return dt
+
+    def orbit_leg(the_wl, the_scene, n_frames, n_warm, in_flight, solo=False):
         """Frame k of the workload's 64-frame orbit on rank k mod world, n_frames timed per rank after n_warm untimed;
-        cameras pre-rendered once (cached host set-up: this leg measures the GPU path).  -> (seconds, total steps,
-        check callable)."""
-        mine = strips.orbit_frames_of_rank(rank, world, n_warm + n_frames, ORBIT_FRAMES)
+        cameras pre-rendered once (cached host set-up: this leg measures the GPU path).  solo: rank 0 alone renders
+        frames 0, 1, 2, .. (the one-GPU reference of the same leg); the others only stand in the barriers.
+        -> (seconds, total steps, check callable)."""
+        if solo and rank != 0:
+            return timed(lambda: None, n_frames), total_over_ranks(0), lambda: None
+        mine = strips.orbit_frames_of_rank(0 if solo else rank, 1 if solo else world, n_warm + n_frames, ORBIT_FRAMES)
         cams = {k: the_wl.camera(k, ORBIT_FRAMES) for k in sorted(set(mine))}
         steps_of = {k: int(the_scene.render_stats(c)[1].steps) for k, c in cams.items()}  # untimed, instrumented
         keep, lanes = make_lanes(in_flight, the_wl.width, the_wl.height)
@@ -276,43 +492,116 @@ def main():
         del keep
         return dt, total_over_ranks(sum(steps_of[k] for k in mine[n_warm:])), check
 
-    # Untimed, before any warm-up step: the library calibrates the launch order of a camera it sees repeatedly from a few
-    # measured launches (csrc/launch_order.cpp plan_order_from_measurement; each needs the previous one finished, which a
-    # renderer that presents its frames does by itself and a loop that queues hundreds of launches ahead does not):
-    # a dozen launches of the static pose with a synchronisation in between, then 50 more so that the GPUs enter the
-    # timed region at steady clocks.
-    for _ in range(12):
-        scene.bench_kernel_ms(cam, 1)
-    scene.bench_kernel_ms(cam, 50)
+    def strips_block(the_wl, the_scene, n_frames):
+        """ONE frame of the_wl in cyclic 16-row bands over the ranks (BASELINE configs[3]'s sharding): kernel only, strips
+        gathered to rank 0 over RCCL, every rank's strip to its own pinned host memory; and the same three on ONE GPU
+        (rank 0 renders the whole frame while the others wait) for the speed-up of this run."""
+        cam4 = the_wl.camera()
+        W4, H4 = cam4.width, cam4.height
+        fb4, st4, _, _ = the_scene.render_stats(cam4)  # (every rank: its own check frame and the step count)
+        steps4 = int(st4.steps)
+        result = {}
+
+        def legs_for(plan, the_rank, active):
+            strip = torch.zeros((plan.strip_rows, W4, 4), dtype=torch.uint8, device="cuda") if active else None
+            block = torch.zeros((plan.world, plan.strip_rows, W4, 4), dtype=torch.uint8, device="cuda") if (active and the_rank == 0 and plan.world > 1) else None
+            host_strip = torch.zeros((plan.strip_rows, W4, 4), dtype=torch.uint8).pin_memory() if active else None
+
+            def render_rows4(strip_t, band_rows, band_index, band_count):
+                the_scene.render_rows_device(cam4, strip_t.data_ptr(), W4 * 4, band_rows=band_rows,
+                                             band_index=band_index, band_count=band_count, stream=stream)
+
+            def step_kernel():
+                render_rows4(strip, plan.band_rows, the_rank, plan.world)
+
+            def step_gather():
+                result["frame4"] = strips.render_frame_distributed(plan, the_rank, render_rows4, job.dist if plan.world > 1 else None, strip, block)
+
+            def step_own():
+                strips.render_strip_to_host(plan, the_rank, render_rows4, strip, host_strip)
+            legs = {}
+            for name, fn in (("kernel_only", step_kernel), ("gather_to_rank0_over_rccl", step_gather), ("own_pcie_link_no_collective", step_own)):
+                if active:
+                    for _ in range(3):
+                        fn()
+                dt4 = timed(fn if active else (lambda: None), n_frames)
+                legs[name] = {"ms_per_frame": dt4 * 1e3 / n_frames, "value": steps4 * n_frames / dt4}
+            ok = True
+            if active:
+                ok = strips.strip_rows_match(plan, the_rank, host_strip.numpy(), fb4)
+                if the_rank == 0:
+                    ok = ok and np.array_equal(result["frame4"].cpu().numpy(), fb4)
+            if total_over_ranks(0 if ok else 1):
+                raise SystemExit("bench.py: a c4_strips leg produced different pixels than hmrm_render_stats")
+            return legs
+        legs_n = legs_for(strips.BandPlan(height=H4, width=W4, band_rows=BAND_ROWS, world=world), rank, True)
+        block = {"workload": workload_text(the_wl) + f"; cyclic {BAND_ROWS}-row bands over {world} GPU(s)",
+                 "frames": n_frames, "ray_steps_per_frame": steps4, "unit": "ray-steps/s", "scaling": "strong"}
+        if world > 1:
+            legs_1 = legs_for(strips.BandPlan(height=H4, width=W4, band_rows=BAND_ROWS, world=1), 0, rank == 0)
+            legs_1["gather_to_rank0_over_rccl"]["note"] = "one GPU: no gather, the strip is the frame (reassembly only)"
+            block["one_gpu_same_run"] = legs_1
+            for name, leg in legs_n.items():
+                leg["speedup_vs_one_gpu"] = legs_1[name]["ms_per_frame"] / leg["ms_per_frame"]
+                leg["efficiency"] = leg["speedup_vs_one_gpu"] / world
+        block.update(legs_n)
+        return block
+
+    def executed(st_):
+        return {"height_samples": int(st_.groups) * 4 if st_.groups else None, "pyramid_lookups": int(st_.leap_attempts),
+                "steps_covered_by_exact_leaps": int(st_.leaped_steps)}
+
+    def workload_block(w, the_scene, n_frames, n_warm):
+        """One more BASELINE configuration on this GPU: static pose, one stream, like the headline."""
+        c = w.camera()
+        fb, s_, _, _ = the_scene.render_stats(c)
+        precondition(the_scene, c)
+        dt = static_leg(the_scene, c, n_frames, n_warm, 1, fb)
+        kms = the_scene.bench_kernel_ms(c, min(50, max(10, n_frames)))
+        return {"workload": workload_text(w), "frames": n_frames, "ms_per_step": dt * 1e3 / n_frames, "kernel_ms": kms,
+                "value": int(s_.steps) * n_frames / dt, "unit": "ray-steps/s", "equivalent_steps": True,
+                "mrays_per_s": int(s_.rays) * n_frames / dt / 1e6, "ray_steps_per_frame": int(s_.steps),
+                "rays_per_frame": int(s_.rays), "hits_per_frame": int(s_.hits), "executed_per_frame": executed(s_)}
+
+    def with_kernel(name, fn):
+        """Run fn() with HMRM_KERNEL=name (the library re-reads the knob for live scenes; launch orders calibrated for
+        another variant are forgotten), then restore."""
+        old = os.environ.get("HMRM_KERNEL")
+        os.environ["HMRM_KERNEL"] = name
+        try:
+            return fn()
+        finally:
+            if old is None:
+                os.environ.pop("HMRM_KERNEL", None)
+            else:
+                os.environ["HMRM_KERNEL"] = old
+
+    precondition(scene, cam)
 
     result = {}
+    extra = {}
     in_flight = max(1, min(args.frames_in_flight, 4))
     if not multi:
-        keep0, lanes = make_lanes(in_flight)
-        nxt, _ = round_robin(lanes)
-
-        def step():
-            st_, o_ = nxt()
-            scene.render_rows_device(cam, o_.data_ptr(), W * 4, 0, H, stream=st_)
-        for _ in range(args.warmup):
-            step()
-        elapsed = timed(step, args.steps)
+        elapsed = static_leg(scene, cam, args.steps, args.warmup, in_flight, fb_ref)
         total_steps_timed = frame_steps * args.steps
         rays_timed = frame_rays * args.steps
         scaling = "weak"
         parallelism = "1 GPU, launches back to back on one stream" if in_flight == 1 else \
                       f"1 GPU, {in_flight} frames in flight on {in_flight} HIP streams"
-
-        def check_headline():
-            for st_, o_ in lanes[:min(in_flight, args.warmup + args.steps)]:
-                if not np.array_equal(o_.cpu().numpy(), fb_ref):
-                    raise SystemExit("bench.py: timed path produced a different frame than hmrm_render_stats")
     elif args.mode == "frames":
         elapsed, total_steps_timed, check_headline = orbit_leg(wl, scene, args.steps, args.warmup, in_flight)
+        check_headline()
         rays_timed = frame_rays * args.steps * world
         scaling = "weak"
         parallelism = (f"{ORBIT_FRAMES}-frame orbit, frame k on GPU k mod {world} ({args.steps} frames per GPU), "
                        f"no collective" + (f"; {in_flight} frames in flight per GPU" if in_flight > 1 else ""))
+        # the same leg on ONE GPU, same run: rank 0 renders frames 0 .. K-1 of the orbit alone
+        dt1, steps1, check1 = orbit_leg(wl, scene, args.steps, min(args.warmup, 8), in_flight, solo=True)
+        check1()
+        extra["one_gpu_same_leg"] = {"ms_per_step": dt1 * 1e3 / args.steps, "value": steps1 / dt1, "frames": args.steps,
+                                     "note": "rank 0 alone renders frames 0 .. K-1 of the same orbit while the other ranks wait"}
+        extra["speedup_vs_one_gpu"] = (total_steps_timed / elapsed) / (steps1 / dt1)
+        extra["efficiency_vs_one_gpu"] = extra["speedup_vs_one_gpu"] / world
     else:
         plan = strips.BandPlan(height=H, width=W, band_rows=BAND_ROWS, world=world)
         strip = torch.zeros((plan.strip_rows, W, 4), dtype=torch.uint8, device="cuda")
@@ -323,7 +612,7 @@ def main():
                                      band_index=band_index, band_count=band_count, stream=stream)
 
         def step():
-            result["frame"] = strips.render_frame_distributed(plan, rank, render_rows, dist, strip, block)
+            result["frame"] = strips.render_frame_distributed(plan, rank, render_rows, job.dist, strip, block)
         for _ in range(args.warmup):
             step()
         elapsed = timed(step, args.steps)
@@ -331,117 +620,138 @@ def main():
         rays_timed = frame_rays * args.steps
         scaling = "strong"
         parallelism = f"cyclic {BAND_ROWS}-row bands over {world} GPUs + RCCL gather to rank 0"
-
-        def check_headline():
-            if rank == 0 and not np.array_equal(result["frame"].cpu().numpy(), fb_ref):
-                raise SystemExit("bench.py: timed path produced a different frame than hmrm_render_stats")
+        if rank == 0 and not np.array_equal(result["frame"].cpu().numpy(), fb_ref):
+            raise SystemExit("bench.py: timed path produced a different frame than hmrm_render_stats")
 
     # dominant kernel: mean launch duration by HIP events on the launch stream (full frame, static pose, back to back)
     kernel_ms = scene.bench_kernel_ms(cam, 50) if rank == 0 else None
-    # correctness of what was just timed, against the instrumented kernel (another instantiation, host read-back path)
-    check_headline()
 
     secondary = {}
     if not args.no_secondary and not multi:
         # ---- three frames in flight (a throughput mode for sequences of independent frames, hmap.cpp:1131-1144)
-        keep3, lanes3 = make_lanes(3)
-        nxt3, _ = round_robin(lanes3)
-
-        def step3():
-            st_, o_ = nxt3()
-            scene.render_rows_device(cam, o_.data_ptr(), W * 4, 0, H, stream=st_)
-        for _ in range(50 + args.warmup):
-            step3()
-        dt3 = timed(step3, args.steps)
-        for st_, o_ in lanes3:
-            if not np.array_equal(o_.cpu().numpy(), fb_ref):
-                raise SystemExit("bench.py: a frame in flight differs from hmrm_render_stats")
+        dt3 = static_leg(scene, cam, args.steps, 50 + args.warmup, 3, fb_ref)
         secondary["frames_in_flight"] = {"streams": 3, "ms_per_step": dt3 * 1e3 / args.steps,
                                          "value": frame_steps * args.steps / dt3,
                                          "note": "same K frames round-robin over 3 HIP streams; not the operating point of `roofline`"}
-        del keep3, lanes3
 
         # ---- a moving camera: every timed frame's camera is new to the library (no pre-render), then the same
         # cameras again (per-stream cache of 64 records).  One stream, back to back, like the headline.
-        def fresh_leg(the_wl, tag):
+        def fresh_leg(the_wl, the_scene, tag):
             n = min(args.steps, 60)
             out_t = torch.empty((the_wl.height, the_wl.width, 4), dtype=torch.uint8, device="cuda")
             base = the_wl.camera()
             # orbit positions no other part of this run has used (a 1000003-frame orbit, frames 1..n)
             cams = [the_wl.camera(k, 1000003) for k in range(1, n + 1)]
             for _ in range(30):  # steady clocks
-                scene.render_rows_device(base, out_t.data_ptr(), the_wl.width * 4, 0, the_wl.height, stream=stream)
+                the_scene.render_rows_device(base, out_t.data_ptr(), the_wl.width * 4, 0, the_wl.height, stream=stream)
             it = iter(cams)
 
             def step_f():
-                scene.render_rows_device(next(it), out_t.data_ptr(), the_wl.width * 4, 0, the_wl.height, stream=stream)
+                the_scene.render_rows_device(next(it), out_t.data_ptr(), the_wl.width * 4, 0, the_wl.height, stream=stream)
             fresh = timed(step_f, n)
             it = iter(cams)
             cached = timed(step_f, n)
-            if not np.array_equal(out_t.cpu().numpy(), scene.render_stats(cams[-1])[0]):
+            last_fb, last_st, _, _ = the_scene.render_stats(cams[-1])
+            if not np.array_equal(out_t.cpu().numpy(), last_fb):
                 raise SystemExit(f"bench.py: fresh-camera leg ({tag}) rendered a different frame than hmrm_render_stats")
+            steps_all = sum(int(the_scene.render_stats(c)[1].steps) for c in cams)  # (after the timing: untimed, instrumented)
             return {"frames": n, "ms_per_step": fresh * 1e3 / n, "cached_ms_per_step": cached * 1e3 / n,
-                    "fresh_over_cached": fresh / cached}
-        fc = fresh_leg(wl, wl.name)
+                    "fresh_over_cached": fresh / cached, "value": steps_all / fresh, "unit": "ray-steps/s",
+                    "mrays_per_s": n * the_wl.width * the_wl.height / fresh / 1e6}
+        fc = fresh_leg(wl, scene, wl.name)
         fc["note"] = ("every timed frame has a camera the library has not seen: per-frame host set-up (libm, spherical "
                       "sin/cos tables on the host pool, upload) inside the loop; then the same cameras from the cache")
-        if wl.map_size == 4096 and wl.name != "C5":
-            fc["C5"] = fresh_leg(hmrm.synth.WORKLOADS["C5"], "C5")  # (perspective; same maps and scene parameters)
+        extra["value_moving_camera"] = fc["value"]
+        if wl.map_size == 4096 and wl.content == "smooth" and wl.name != "C5":
+            fc["C5"] = fresh_leg(synth.WORKLOADS["C5"], scene, "C5")  # (perspective; same maps and scene parameters)
         secondary["fresh_camera"] = fc
+
+        # ---- the kernel that executes every one of the reference's loads, on the headline frame: the one kernel
+        # SURVEY 8(d)'s algorithmic-bytes fraction is defined for
+        def literal():
+            scene.bench_kernel_ms(cam, 1)
+            return scene.bench_kernel_ms(cam, 3)
+        lit_ms = with_kernel("simple", literal)
+        lit_pmc, lit_prov = _pmc_from_profiles(wl.name + "_literal", hmrm.kernel_src_sha())
+        lit_traffic = lit_pmc.get("hbm_bytes_per_launch") if lit_pmc else None
+        secondary["literal_kernel"] = {
+            "kernel": "k_render (HMRM_KERNEL=simple): main/hmap.cpp:1000-1038 as written, one dependent 8-byte load per ray-step",
+            "launches": 3, "kernel_ms": lit_ms, "value": frame_steps / (lit_ms * 1e-3), "unit": "ray-steps/s (executed, not equivalent)",
+            "production_speedup": lit_ms / kernel_ms,
+            "roofline": {"bound": "hbm", "achieved": algo_bytes / (lit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algo_bytes / (lit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
+                         "traffic": lit_traffic,
+                         "traffic_over_algorithmic": (lit_traffic / algo_bytes) if lit_traffic else None, "pmc": lit_prov}}
+
+        # ---- the other BASELINE configurations on this GPU
+        n_w = max(5, min(args.steps, 50))
+        blocks = {}
+        if wl.name == "C3":
+            blocks["C3h"] = workload_block(synth.WORKLOADS["C3h"], scene, n_w, 5)
+            blocks["C5"] = workload_block(synth.WORKLOADS["C5"], scene, n_w, 5)
+            w2 = synth.WORKLOADS["C2"]
+            scene2 = hmrm.Scene(*maps_of(w2), w2.scene_params())
+            blocks["C2"] = workload_block(w2, scene2, n_w, 5)
+            scene2.close()
+        secondary["workloads"] = blocks
+
+        # ---- maps built to defeat the traversal: production kernel against the plain 4-step groups
+        if not args.no_rough and wl.content == "smooth":
+            rough = {}
+            n_r = max(3, min(args.steps, 10))
+            for kind in ("white", "spikes", "needles", "canyon"):
+                wr = synth.content_workload(wl.name, kind)
+                sc = hmrm.Scene(*wr.maps(), wr.scene_params())
+                cr = wr.camera()
+                fbr, sr, _, _ = sc.render_stats(cr)
+                precondition(sc, cr)
+                leap_ms = sc.bench_kernel_ms(cr, n_r)
+
+                def group():
+                    sc.bench_kernel_ms(cr, 2)
+                    return sc.bench_kernel_ms(cr, n_r)
+                group_ms = with_kernel("group", group)
+                if not np.array_equal(sc.render(cr), fbr):
+                    raise SystemExit(f"bench.py: rough_terrain/{kind}: hmrm_render and hmrm_render_stats disagree")
+                rough[kind] = {"workload": workload_text(wr), "kernel_ms": leap_ms, "group_kernel_ms": group_ms,
+                               "leap_over_group": leap_ms / group_ms, "ray_steps_per_frame": int(sr.steps),
+                               "value": int(sr.steps) / (leap_ms * 1e-3), "mrays_per_s": int(sr.rays) / (leap_ms * 1e-3) / 1e6,
+                               "executed_per_frame": executed(sr)}
+                sc.close()
+            rough["note"] = ("same camera as the headline (canyon: low and level, down the corridor); kernel_ms by HIP events, "
+                             f"{n_r} launches; group_kernel_ms = HMRM_KERNEL=group (speculative 4-step groups, no leaps)")
+            secondary["rough_terrain"] = rough
+
+        # ---- C4 on one GPU (8192^2 maps: the scene of the headline is released first)
+        if not args.no_c4 and wl.name == "C3":
+            w4 = synth.WORKLOADS["C4"]
+            scene4 = hmrm.Scene(*w4.maps(), w4.scene_params())
+            blocks["C4"] = workload_block(w4, scene4, max(5, min(args.steps, 20)), 3)
+            scene4.close()
         torch.cuda.synchronize()
     elif not args.no_secondary and multi and args.mode == "frames":
-        # ---- BASELINE config C5: the recording's camera (perspective), frame k on GPU k mod N; same maps
-        if wl.map_size == 4096 and wl.name != "C5":
-            wl5 = hmrm.synth.WORKLOADS["C5"]
-            n5 = min(args.steps, 64)
-            dt5, steps5, check5 = orbit_leg(wl5, scene, n5, min(args.warmup, 8), 1)
-            check5()
-            secondary["c5_frames"] = {"workload": "C5: 4096^2, 3840x2160, perspective hfov 90, step_dist 0.5, 64-frame orbit, frame k on GPU k mod N",
-                                      "frames_per_gpu": n5, "ms_per_step": dt5 * 1e3 / n5, "value": steps5 / dt5,
-                                      "unit": "ray-steps/s", "scaling": "weak"}
-        # ---- BASELINE config C4: one 7680x4320 orthographic frame over the 8192^2 map in cyclic 16-row bands
+        # ---- the N = 1 line's own step on every GPU (C3's static pose, one stream): comparable with that line's `value`
+        w3 = synth.WORKLOADS["C3"]
+        if w3.map_size == wl.map_size and wl.content == "smooth":
+            c3 = w3.camera()
+            fb3, st3, _, _ = scene.render_stats(c3)
+            precondition(scene, c3)
+            dt_all = static_leg(scene, c3, args.steps, args.warmup, 1, fb3)
+            dt_one = static_leg(scene, c3, args.steps, args.warmup, 1, fb3, active=rank == 0)
+            secondary["static_pose_replicas"] = {
+                "workload": workload_text(w3), "frames_per_gpu": args.steps, "ms_per_step": dt_all * 1e3 / args.steps,
+                "value": int(st3.steps) * args.steps * world / dt_all, "unit": "ray-steps/s", "scaling": "weak",
+                "one_gpu_same_run": {"ms_per_step": dt_one * 1e3 / args.steps, "value": int(st3.steps) * args.steps / dt_one},
+                "efficiency_vs_one_gpu": dt_one / dt_all,
+                "note": "every GPU renders the N = 1 line's step (same pose, K frames, one stream); no collective"}
+        # ---- BASELINE configs[3]: one 7680x4320 orthographic frame over the 8192^2 map in cyclic 16-row bands
         if not args.no_c4:
             scene.close()
             scene = None
-            wl4 = hmrm.synth.WORKLOADS["C4"]
-            rgb4, cmap4 = hmrm.synth.synth_maps(wl4.map_size)
-            cam4 = wl4.camera()
-            scene4 = hmrm.Scene(rgb4, cmap4, wl4.scene_params())
-            del rgb4, cmap4
-            W4, H4 = cam4.width, cam4.height
-            fb4, st4, _, _ = scene4.render_stats(cam4)  # (every rank: its own check frame and the step count)
-            plan = strips.BandPlan(height=H4, width=W4, band_rows=BAND_ROWS, world=world)
-            strip = torch.zeros((plan.strip_rows, W4, 4), dtype=torch.uint8, device="cuda")
-            block = torch.zeros((world, plan.strip_rows, W4, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
-            host_strip = torch.zeros((plan.strip_rows, W4, 4), dtype=torch.uint8).pin_memory()
-
-            def render_rows4(strip_t, band_rows, band_index, band_count):
-                scene4.render_rows_device(cam4, strip_t.data_ptr(), W4 * 4, band_rows=band_rows,
-                                          band_index=band_index, band_count=band_count, stream=stream)
-            n4 = max(5, min(args.steps, 40))
-
-            def step_gather():
-                result["frame4"] = strips.render_frame_distributed(plan, rank, render_rows4, dist, strip, block)
-
-            def step_own():
-                strips.render_strip_to_host(plan, rank, render_rows4, strip, host_strip)
-
-            def step_kernel():
-                render_rows4(strip, plan.band_rows, rank, plan.world)
-            legs = {}
-            for name, fn in (("kernel_only", step_kernel), ("gather_to_rank0_over_rccl", step_gather), ("own_pcie_link_no_collective", step_own)):
-                for _ in range(3):
-                    fn()
-                dt4 = timed(fn, n4)
-                legs[name] = {"ms_per_frame": dt4 * 1e3 / n4, "value": int(st4.steps) * n4 / dt4}
-            ok4 = strips.strip_rows_match(plan, rank, host_strip.numpy(), fb4)
-            if rank == 0:
-                ok4 = ok4 and np.array_equal(result["frame4"].cpu().numpy(), fb4)
-            if total_over_ranks(0 if ok4 else 1):
-                raise SystemExit("bench.py: a c4_strips leg produced different pixels than hmrm_render_stats")
-            secondary["c4_strips"] = {"workload": f"C4: 8192^2, {W4}x{H4}, orthographic, step_dist 0.5, cyclic {BAND_ROWS}-row bands over {world} GPUs",
-                                      "frames": n4, "ray_steps_per_frame": int(st4.steps), "unit": "ray-steps/s",
-                                      "scaling": "strong", **legs}
+            maps_cache.clear()
+            wl4 = synth.WORKLOADS["C4"]
+            scene4 = hmrm.Scene(*wl4.maps(), wl4.scene_params())
+            secondary["c4_strips"] = strips_block(wl4, scene4, max(5, min(args.steps, 40)))
             scene4.close()
 
     if rank == 0:
@@ -476,11 +786,13 @@ def main():
             "hbm": {"achieved": (traffic / kernel_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None},
             "lane_util": (pmc or {}).get("lane_util"),
+            "wave_time": (pmc or {}).get("wave_time"),
             "kernel": "k_render_fast", "kernel_ms": kernel_ms,
             "kernel_ray_steps_per_s": frame_steps / kernel_s,
-            "operating_point": "launches back to back on one stream (the same as `value` at N = 1)",
+            "operating_point": "launches of the workload's static pose back to back on one stream (the same as `value` at N = 1)",
             # BASELINE.md's nominal figure: bytes the REFERENCE's loop would move for this frame over the
             # measured duration.  Not executed traffic (the loads are skipped), hence not a fraction of a peak.
+            # (The kernel that does execute them: `literal_kernel.roofline`.)
             "algorithmic_equivalent": {"bytes_per_launch": algo_bytes, "gbs": algo_bytes / kernel_s / 1e9,
                                        "times_hbm_peak": algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS},
             "pmc": prov,
@@ -488,6 +800,12 @@ def main():
         if pmc and pmc.get("in_flight"):
             # VALU-busy over the overlapped window of three frames in flight (its own PMC pass, tools/profile_round.sh)
             secondary.setdefault("frames_in_flight", {})["pmc"] = pmc["in_flight"]
+        for name, blk in (secondary.get("workloads") or {}).items():
+            p2, prov2 = _pmc_from_profiles(name, hmrm.kernel_src_sha())
+            if p2 and (p2.get("valu") or {}).get("busy_cycles_isa"):
+                blk["valu_frac"] = p2["valu"]["busy_cycles_isa"] / (blk["kernel_ms"] * 1e-3) / 1e9 / peak
+                blk["hbm_bytes_per_launch"] = p2.get("hbm_bytes_per_launch")
+                blk["pmc_source"] = prov2.get("source")
         line = {
             "metric": "ray-steps/s at 3840x2160, 4096^2 heightmap" if wl.map_size == 4096 else
                       f"ray-steps/s at {W}x{H}, {wl.map_size}^2 heightmap",
@@ -497,32 +815,29 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "equivalent_steps": True,
             "frames_in_flight": in_flight,
-            "executed_per_frame": {"height_samples": int(st.groups) * 4 if st.groups else None,
-                                   "pyramid_lookups": int(st.leap_attempts),
-                                   "steps_covered_by_exact_leaps": int(st.leaped_steps)},
+            "preconditioning": f"{PRECONDITION_LAUNCHES} synchronised launches of the pose (launch-order calibration), then 50 queued ones, untimed",
+            "executed_per_frame": executed(st),
             "mrays_per_s": rays_timed / elapsed / 1e6,
-            "config": {"workload": f"{wl.name}: {wl.map_size}x{wl.map_size} heightmap, {W}x{H}, "
-                                   f"{('perspective', 'spherical', 'orthographic')[wl.projection - 1]} "
-                                   f"hfov {wl.hfov_deg:g}, step_dist {wl.step_dist:g}, grid_width 1",
+            "config": {"workload": workload_text(wl),
                        "ray_steps_per_frame": frame_steps, "rays_per_frame": frame_rays,
                        "hits_per_frame": frame_hits, "parallelism": parallelism,
-                       "maps_sha256": hmrm.synth.maps_sha256(rgb, cmap)[:16]},
+                       "maps_sha256": synth.maps_sha256(rgb, cmap)[:16]},
             "roofline": roofline,
         }
-        if rccl_ranks is not None:
-            line["rccl_ranks"] = rccl_ranks
+        line.update(extra)
+        if job.rccl_ranks is not None:
+            line["rccl_ranks"] = job.rccl_ranks
         line.update(secondary)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hmrm, wl, rgb, cmap, params, cam, args.cpu_seconds)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    job.finish()
     if scene is not None:
         scene.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

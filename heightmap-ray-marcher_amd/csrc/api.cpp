@@ -191,6 +191,7 @@ struct hmrm_scene {
 	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/8/../256-cell windows every 2/4/../128 cells
 	int32_t mip_w[hmrm::kMipLevels] = {}, mip_h[hmrm::kMipLevels] = {};
 	int32_t mip_row = 0, mip_plane_shift = 0; // plane layout of both pyramids, see DevFrame
+	bool mip_offsets_fit = true; // every look-up's byte offset fits 32 bits (hmrm_scene_create); else the literal loop renders
 	size_t mip_floats() const { return (size_t)(hmrm::kMipLevels + 1) << mip_plane_shift; }
 	float *plane(float *buf, int l) const { return buf + ((size_t)l << mip_plane_shift); }
 	hipStream_t stream = nullptr; // the scene's own stream (hmrm_render, updates)
@@ -201,6 +202,8 @@ struct hmrm_scene {
 	// scratch of the host-memory entry points (hmrm_render*, one caller at a time)
 	uint32_t *d_frame = nullptr;
 	size_t frame_px = 0;
+	uint8_t *h_stage = nullptr; // pinned staging strip of hmrm_render_multi (pageable destination frames)
+	size_t h_stage_bytes = 0;
 	uint32_t *d_steps = nullptr;
 	double *d_entry = nullptr;
 	size_t stats_px = 0;
@@ -219,6 +222,10 @@ struct hmrm_scene {
 	};
 	std::vector<SettledOrder> settled;
 };
+
+// cached records and settled launch orders are looked up with memcmp on these two: no padding bytes allowed
+static_assert(sizeof(hmrm_camera) == 3 * sizeof(int32_t) + 4 + 8 * sizeof(double), "hmrm_camera has padding");
+static_assert(sizeof(hmrm_scene_params) == 6 * sizeof(double), "hmrm_scene_params has padding");
 
 struct hmrm_config {
 	hmrm::Config cfg;
@@ -549,8 +556,10 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 	}
 	// the production kernel indexes cells and windows with 24-bit multiplies (leap_common.hpp index_2d): a map
 	// with a side of 2^24 cells or more (then at most 32 cells the other way) goes through the literal loop
-	const bool huge_side = s->map_w >= (1 << 24) || s->map_h >= (1 << 24);
-	if (huge_side && f.sampling != 0) return fail(HMRM_E_ARG, "maps with a side of 2^24 cells or more support nearest sampling only");
+	// ... and so does one whose pyramid planes are too far apart for the look-up's 32-bit byte offsets (hmrm_scene_create)
+	const bool huge_side = s->map_w >= (1 << 24) || s->map_h >= (1 << 24) || !s->mip_offsets_fit;
+	if (huge_side && f.sampling != 0)
+		return fail(HMRM_E_ARG, "maps with a side of 2^24 cells or more, or more than 2^27 level-0 pyramid windows, support nearest sampling only");
 	if ((s->knobs.kernel == 2 || huge_side) && f.sampling == 0) { // (the literal loop only knows the reference's sampling)
 		HIP_TRY(hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters, d_steps,
 		                            d_entry, stats, c->stream));
@@ -569,6 +578,24 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 	// (only streams other than the scene's own can be recycled, ctx_for)
 	if (c->stream != s->stream) HIP_TRY(hipEventRecord(c->last_launch, c->stream));
 	return HMRM_OK;
+}
+
+// Pyramid layout of a map (DevFrame): windows per level, the common row pitch (level 0's) and the log2 of the
+// power-of-two plane pitch.  Returns whether every look-up's byte offset fits 32 bits: k_render_fast forms
+// ((lev << shift) + index) * 4 in 32 bits, so (kMipLevels + 1) << shift must not exceed 2^30 floats.  Every
+// square-ish map up to hmrm_scene_create's 2^29-cell limit fits (shift <= 27); a very oblong one (16385 x 32766:
+// level 0 has 8193 x 16383 windows, shift 28) does not and is rendered by the literal loop (launch_frame), like
+// maps with a side of 2^24 cells.
+bool mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_w, int32_t *mip_h, int32_t *mip_row, int32_t *plane_shift) {
+	for (int l = 0; l < hmrm::kMipLevels; ++l) {
+		const int stride = 1 << hmrm::mip_stride_shift(l); // windows of win_cells(l) cells every stride cells
+		mip_w[l] = (map_w + stride - 1) / stride;
+		mip_h[l] = (map_h + stride - 1) / stride;
+	}
+	*mip_row = mip_w[0];
+	*plane_shift = 0;
+	while (((size_t)1 << *plane_shift) < (size_t)hmrm::mip_index(mip_w[0] - 1, mip_h[0] - 1, *mip_row) + 1) ++*plane_shift;
+	return ((uint64_t)(hmrm::kMipLevels + 1) << *plane_shift) <= ((uint64_t)1 << 30);
 }
 
 int ensure_frame(hmrm_scene *s, size_t px) {
@@ -724,16 +751,9 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 		HIP_TRY(hipMalloc((void **)&s->d_rgb, n * 3));
 		HIP_TRY(hipMalloc((void **)&s->d_cmap, n * 4));
 		HIP_TRY(hipMalloc((void **)&s->d_thr, n * sizeof(double)));
-		for (int l = 0; l < hmrm::kMipLevels; ++l) {
-			const int stride = 1 << hmrm::mip_stride_shift(l); // windows of win_cells(l) cells every stride cells
-			s->mip_w[l] = (map_w + stride - 1) / stride;
-			s->mip_h[l] = (map_h + stride - 1) / stride;
-		}
 		// every plane has level 0's row pitch and a power-of-two plane pitch (DevFrame); the pyramid of the
 		// bilinear mode is allocated by its first frame
-		s->mip_row = s->mip_w[0];
-		while (((size_t)1 << s->mip_plane_shift) < (size_t)hmrm::mip_index(s->mip_w[0] - 1, s->mip_h[0] - 1, s->mip_row) + 1)
-			++s->mip_plane_shift;
+		s->mip_offsets_fit = mip_layout(map_w, map_h, s->mip_w, s->mip_h, &s->mip_row, &s->mip_plane_shift);
 		HIP_TRY(hipMalloc((void **)&s->d_mipbuf, s->mip_floats() * sizeof(float)));
 		HIP_TRY(hipMalloc((void **)&s->d_maxkey, sizeof(unsigned long long)));
 		HIP_TRY(hipMemcpyAsync(s->d_rgb, height_rgb, n * 3, hipMemcpyHostToDevice, s->stream));
@@ -790,6 +810,7 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (s->d_mipbuf_bil) (void)hipFree(s->d_mipbuf_bil);
 	if (s->d_maxkey) (void)hipFree(s->d_maxkey);
 	if (s->d_frame) (void)hipFree(s->d_frame);
+	if (s->h_stage) (void)hipHostFree(s->h_stage);
 	if (s->d_steps) (void)hipFree(s->d_steps);
 	if (s->d_entry) (void)hipFree(s->d_entry);
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -800,8 +821,23 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 
 int hmrm_debug_reload_env(hmrm_scene *s) {
 	if (!s) return fail(HMRM_E_ARG, "NULL argument");
+	HIP_TRY(hipSetDevice(s->device));
 	std::lock_guard<std::mutex> lk(s->mu);
 	s->knobs = read_knobs();
+	// A launch order is calibrated for ONE kernel variant and level policy: makespans measured before the knobs
+	// changed must not be compared with ones measured after, and an order settled for the old kernel must not be
+	// adopted for the new one.  Every record goes back to "uncalibrated" (pixels never depended on any of this).
+	s->settled.clear();
+	for (StreamCtx *c : s->ctxs)
+		for (FrameSlot &sl : c->slots) {
+			if (sl.trial_in_flight >= 0 && sl.measured) HIP_TRY(hipEventSynchronize(sl.measured)); // (its read-back targets the slot's records)
+			sl.trial_in_flight = -1;
+			sl.order_best = -1;
+			sl.n_trials = 1;
+			for (FrameSlot::OrderTrial &t : sl.trials) t = FrameSlot::OrderTrial();
+			sl.uses = 0;
+			if (c->meas_owner == &sl) c->meas_owner = nullptr;
+		}
 	return HMRM_OK;
 }
 
@@ -951,10 +987,17 @@ int hmrm_render_rows_device(const hmrm_scene *scene, const hmrm_camera *cam, voi
 }
 
 // One frame over several scenes -- one per GPU, same maps (BASELINE config C4's sharding):
-// scene i renders the cyclic 16-row bands i, i+n, ... into a strip on its own device and copies each
-// band straight to its rows of the caller's frame over its own PCIe link; no exchange between devices
-// (a gather to one GPU first would funnel every byte through that GPU's link).  Launches of all
-// devices are enqueued before any is waited for.
+// scene i renders the cyclic 16-row bands i, i+n, ... into a strip on its own device and the strip crosses
+// its own PCIe link; no exchange between devices (a gather to one GPU first would funnel every byte through
+// that GPU's link).  Three passes so that no device ever waits for another one's copy:
+//   1. every scene's kernel is launched (asynchronous);
+//   2. every scene's device-to-host copy is enqueued behind its kernel.  A copy into PAGEABLE host memory is staged
+//      by the runtime and blocks the calling thread until it is done -- device i+1's copy would start after device
+//      i's had finished -- so the copies go to the caller's frame directly only when that memory is pinned (the
+//      caller registered it, hipHostRegister, or got it from hipHostMalloc), else to a pinned staging strip the
+//      scene owns;
+//   3. scenes are waited for in order and staged strips are copied into the caller's rows by the host pool while
+//      the later devices' copies are still in flight.
 int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_camera *cam, uint8_t *rgba,
                       size_t stride_bytes) {
 	int rc = check_camera(cam);
@@ -967,22 +1010,52 @@ int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_ca
 	const int n = std::min<int>(n_scenes, (H + kBand - 1) / kBand);
 	for (int i = 0; i < n; ++i)
 		if (!scenes[i]) return fail(HMRM_E_ARG, "NULL scene");
-	// (an error part-way leaves copies of the scenes already launched in flight into the caller's frame: they are
-	// drained before the call returns, the caller may free `rgba` at once)
-	auto enqueue = [&](int i) -> int {
+	// is the caller's frame pinned?  (an address the runtime does not know is ordinary pageable memory: the query
+	// fails with hipErrorInvalidValue, which is not an error of this call)
+	bool pinned_dst = false;
+	{
+		hipPointerAttribute_t attr{};
+		if (hipPointerGetAttributes(&attr, rgba) == hipSuccess) pinned_dst = attr.type == hipMemoryTypeHost;
+		else (void)hipGetLastError();
+	}
+	int launched = 0; // scenes with work in flight: drained before an error return (the caller may free `rgba` at once)
+	auto drain = [&](int rc_keep) -> int {
+		const std::string keep = g_error;
+		for (int j = 0; j < launched; ++j)
+			if (hipSetDevice(scenes[j]->device) == hipSuccess) (void)hipStreamSynchronize(scenes[j]->stream);
+		g_error = keep;
+		return rc_keep;
+	};
+	auto launch = [&](int i) -> int {
 		hmrm_scene *s = scenes[i];
 		HIP_TRY(hipSetDevice(s->device));
 		std::lock_guard<std::mutex> lk(s->mu);
 		const int32_t local = hmrm_band_local_rows(H, kBand, i, n);
 		int rc2;
 		if ((rc2 = ensure_frame(s, W * (size_t)local))) return rc2;
+		if (!pinned_dst && s->h_stage_bytes < W * 4 * (size_t)local) {
+			if (s->h_stage) (void)hipHostFree(s->h_stage);
+			s->h_stage = nullptr;
+			s->h_stage_bytes = 0;
+			HIP_TRY(hipHostMalloc((void **)&s->h_stage, W * 4 * (size_t)local, hipHostMallocDefault));
+			s->h_stage_bytes = W * 4 * (size_t)local;
+		}
 		StreamCtx *c = nullptr;
 		if ((rc2 = ctx_for(s, s->stream, &c))) return rc2;
 		hmrm::DevFrame f;
 		FrameSlot *slot = nullptr;
 		if ((rc2 = prepare_frame(s, c, cam, &f, &slot))) return rc2;
 		hmrm::RowMap rows{0, local, kBand, i, n, {}, {}, nullptr};
-		if ((rc2 = launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc2;
+		return launch_frame(s, c, f, slot, rows, s->d_frame, (int64_t)W, nullptr, nullptr, false);
+	};
+	auto enqueue_copy = [&](int i) -> int {
+		hmrm_scene *s = scenes[i];
+		HIP_TRY(hipSetDevice(s->device));
+		const int32_t local = hmrm_band_local_rows(H, kBand, i, n);
+		if (!pinned_dst) { // the whole strip in one transfer
+			HIP_TRY(hipMemcpyAsync(s->h_stage, s->d_frame, W * 4 * (size_t)local, hipMemcpyDeviceToHost, s->stream));
+			return HMRM_OK;
+		}
 		// band b of this scene's strip is frame rows [(i + b*n) * kBand, ...): contiguous in both
 		for (int b = 0; (i + b * n) * kBand < H; ++b) {
 			const int row0 = (i + b * n) * kBand, nrows = std::min(kBand, H - row0);
@@ -993,24 +1066,34 @@ int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_ca
 		return HMRM_OK;
 	};
 	for (int i = 0; i < n; ++i) {
-		if ((rc = enqueue(i)) != HMRM_OK) {
-			const std::string keep = g_error;
-			for (int j = 0; j <= i; ++j)
-				if (hipSetDevice(scenes[j]->device) == hipSuccess) (void)hipStreamSynchronize(scenes[j]->stream);
-			g_error = keep;
-			return rc;
-		}
+		rc = launch(i);
+		launched = i + 1; // (a failed launch may still have enqueued a table upload)
+		if (rc != HMRM_OK) return drain(rc);
 	}
+	for (int i = 0; i < n; ++i)
+		if ((rc = enqueue_copy(i)) != HMRM_OK) return drain(rc);
 	unsigned long long capped = 0;
 	for (int i = 0; i < n; ++i) {
 		hmrm_scene *s = scenes[i];
-		HIP_TRY(hipSetDevice(s->device));
-		HIP_TRY(hipStreamSynchronize(s->stream));
+		hipError_t e = hipSetDevice(s->device);
+		if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+		if (e != hipSuccess) return drain(fail(HMRM_E_DEVICE, std::string("hmrm_render_multi: ") + hipGetErrorString(e)));
+		if (!pinned_dst) {
+			const int bands = (H - i * kBand + n * kBand - 1) / (n * kBand); // bands i, i+n, .. below H
+			const uint8_t *src = s->h_stage;
+			hmrm::parallel_ranges(bands, 4, [&](int b0, int b1) {
+				for (int b = b0; b < b1; ++b) {
+					const int row0 = (i + b * n) * kBand, nrows = std::min(kBand, H - row0);
+					for (int r = 0; r < nrows; ++r)
+						memcpy(rgba + (size_t)(row0 + r) * stride_bytes, src + ((size_t)b * kBand + (size_t)r) * W * 4, W * 4);
+				}
+			});
+		}
 		std::lock_guard<std::mutex> lk(s->mu);
 		StreamCtx *c = nullptr;
-		if ((rc = ctx_for(s, s->stream, &c))) return rc;
+		if ((rc = ctx_for(s, s->stream, &c))) return drain(rc);
 		unsigned long long here = 0;
-		if ((rc = take_capped(c, &here))) return rc;
+		if ((rc = take_capped(c, &here))) return drain(rc);
 		capped += here;
 	}
 	return capped ? noterm(capped) : HMRM_OK;
@@ -1451,6 +1534,18 @@ int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params, in
 	*o++ = (double)f.grid_pow2;
 	*o++ = f.inv_grid_width;
 	return HMRM_OK;
+}
+
+// Test hook (no GPU): the pyramid layout hmrm_scene_create would choose for a map, and whether the production
+// kernel's 32-bit look-up offsets cover it (0: the scene is rendered by the literal loop).
+int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_t *plane_shift, int32_t *levels) {
+	if (map_w <= 0 || map_h <= 0 || (int64_t)map_w * map_h > ((int64_t)1 << 31) / 4) return fail(HMRM_E_ARG, "bad map dimensions");
+	int32_t w[hmrm::kMipLevels], h[hmrm::kMipLevels], row = 0, shift = 0;
+	const bool fits = mip_layout(map_w, map_h, w, h, &row, &shift);
+	if (mip_row) *mip_row = row;
+	if (plane_shift) *plane_shift = shift;
+	if (levels) *levels = hmrm::kMipLevels;
+	return fits ? 1 : 0;
 }
 
 int32_t hmrm_band_local_rows(int32_t height, int32_t band_rows, int32_t band_index, int32_t band_count) {

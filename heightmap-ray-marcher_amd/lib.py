@@ -105,6 +105,7 @@ def _load():
         "hmrm_render_rows_device": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, i32, i32, i32, i32, i32, vp]),
         "hmrm_scene_take_capped": (C.c_int, [vp, vp, C.POINTER(C.c_uint64)]),
         "hmrm_debug_reload_env": (C.c_int, [vp]),
+        "hmrm_debug_mip_layout": (C.c_int, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "hmrm_band_local_rows": (i32, [i32, i32, i32, i32]),
         "hmrm_render_stats": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(Stats), vp, vp]),
         "hmrm_debug_ray": (C.c_int, [vp, C.POINTER(Camera), i32, i32, dp, dp, dp]),
@@ -344,6 +345,16 @@ def debug_frame(cam: Camera, params: SceneParams, map_w: int, map_h: int):
         rec.update(col_cos_ha=tables[0:W], col_sin_ha=tables[W:2 * W],
                    row_sin_va=tables[2 * W:2 * W + H], row_cos_va=tables[2 * W + H:])
     return rec
+
+
+def mip_layout(map_w: int, map_h: int):
+    """Pyramid layout hmrm_scene_create would choose (no GPU needed) -> (row pitch, log2 plane pitch, levels,
+    production kernel usable: its 32-bit look-up offsets cover every plane)."""
+    row, shift, levels = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib.hmrm_debug_mip_layout(int(map_w), int(map_h), C.byref(row), C.byref(shift), C.byref(levels))
+    if rc < 0:
+        raise HmrmError(rc, last_error())
+    return row.value, shift.value, levels.value, bool(rc)
 
 
 def plan_order(records: np.ndarray, rot: int):

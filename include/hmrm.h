@@ -148,8 +148,10 @@ int hmrm_render(const hmrm_scene *scene, const hmrm_camera *cam,
 /* The same frame rendered by several scenes at once -- one per GPU, each created after
  * hmrm_set_device(i) with the same maps (BASELINE config C4's sharding of main/hmap.cpp:978-983's
  * independent pixels): scene i renders the cyclic 16-row bands i, i+n, ... and copies them to their
- * rows of `rgba` over its own PCIe link; no exchange between devices.  Same pixels and return
- * codes as hmrm_render. */
+ * rows of `rgba` over its own PCIe link; no exchange between devices.  All kernels are launched before any
+ * copy is enqueued and no device waits for another one's copy: into pinned `rgba` (hipHostMalloc /
+ * hipHostRegister by the caller) the bands are copied directly, into pageable memory through a pinned
+ * staging strip per scene and a host copy.  Same pixels and return codes as hmrm_render. */
 int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_camera *cam,
                       uint8_t *rgba, size_t stride_bytes);
 
@@ -238,8 +240,16 @@ int hmrm_debug_plan_order(const uint64_t *records, int32_t tile_rows, int32_t ro
 int hmrm_debug_rcp_error(int32_t mode, uint64_t count, uint64_t seed, int32_t exp_lo, int32_t exp_hi,
                          double *max_rel_err, uint64_t *hist64);
 
+/* Test hook, needs no GPU: the window-maximum pyramid layout hmrm_scene_create chooses for a map_w x map_h map
+ * (row pitch in windows, log2 of the plane pitch, number of levels).  Returns 1 when the production kernel's
+ * 32-bit look-up offsets cover every plane, 0 when they do not (very oblong maps near the 2^29-cell limit, e.g.
+ * 16385 x 32766): such a scene is rendered by the literal loop (main/hmap.cpp:1000-1038 as written), nearest
+ * sampling only.  Negative = HMRM_E_ARG. */
+int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_t *plane_shift, int32_t *levels);
+
 /* The environment knobs (HMRM_KERNEL, HMRM_STEP_CAP, ...) are read once, when a
- * scene is created; this re-reads them for a live scene (tests and tools switch kernel variants). */
+ * scene is created; this re-reads them for a live scene (tests and tools switch kernel variants).  Launch orders
+ * calibrated so far are forgotten (they were measured on the old kernel variant). */
 int hmrm_debug_reload_env(hmrm_scene *scene);
 
 /* Time of the most recent render kernel launch on this thread, measured with
@@ -314,9 +324,9 @@ int          hmrm_config_create_scene(const hmrm_config *cfg, hmrm_scene **out);
  * progressive Huffman, 8-bit; grey, YCbCr, RGB, CMYK/YCCK), BMP (1/4/8-bit palette, 16/24/32-bit,
  * bit fields), TGA (types 1/2/3/9/10/11) and binary PNM (P5/P6).  Pixels equal stb_image v2.27's
  * for every req_comp (16-bit -> 8 by >>8; grey -> RGB replicate; missing alpha = 255).  The other
- * formats the reference's stb reads (GIF, PSD, PIC, Radiance HDR; README.md:75) are refused with
- * HMRM_E_IMAGE and a message naming them; an embedder can decode such a map elsewhere and hand the
- * pixels to hmrm_scene_create.  *out is malloc'ed; free with hmrm_image_free. */
+ * formats the reference's stb reads (README.md:75) are decoded too, with stb's pixels: GIF (first frame),
+ * PSD (8/16-bit RGB, raw or RLE), Softimage PIC and Radiance HDR (stb's float -> 8-bit tone curve).
+ * *out is malloc'ed; free with hmrm_image_free. */
 int  hmrm_image_load(const char *path, int32_t req_comp,
                      uint8_t **out, int32_t *w, int32_t *h, int32_t *comp_in_file);
 int  hmrm_image_load_memory(const uint8_t *bytes, size_t len, int32_t req_comp,

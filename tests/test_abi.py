@@ -138,3 +138,24 @@ def test_header_is_c_and_links_from_a_c_program(hmrm, tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_pyramid_layout_and_the_32_bit_offset_bound(hmrm):
+    """k_render_fast forms a pyramid look-up's byte offset in 32 bits, so a scene whose
+    (levels + 1) planes of 2^shift floats exceed 2^32 bytes must not be rendered by it.  hmrm_scene_create routes such
+    a scene (very oblong maps near the 2^29-cell limit) to the literal loop; this checks the layout rule without a GPU."""
+    for w, h in [(1, 1), (256, 256), (4096, 4096), (8192, 8192), (23170, 23170), (1 << 24, 1), (1, 1 << 24), (16384, 32768),
+                 (16385, 32766), (32766, 16385), (3, 178956970), (536870912, 1)]:
+        row, shift, levels, fits = hmrm.mip_layout(w, h)
+        assert levels == 7
+        assert row == (w + 1) // 2  # level 0: 4-cell windows every 2 cells
+        need = ((h + 1) // 2 - 1) * row + (w + 1) // 2  # last element of level 0's plane + 1
+        assert (1 << shift) >= need and (shift == 0 or (1 << (shift - 1)) < need)
+        assert fits == (((levels + 1) << shift) * 4 <= 1 << 32), (w, h, shift)
+    assert hmrm.mip_layout(4096, 4096)[3] and hmrm.mip_layout(23170, 23170)[3]  # every square map up to the cell limit fits
+    assert not hmrm.mip_layout(16385, 32766)[3]  # the advisor's example: plane shift 28
+    import pytest as _pytest
+    with _pytest.raises(hmrm.HmrmError):
+        hmrm.mip_layout(0, 5)
+    with _pytest.raises(hmrm.HmrmError):
+        hmrm.mip_layout(32768, 32768)  # more than 2^29 cells: hmrm_scene_create refuses the map
