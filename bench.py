@@ -440,9 +440,11 @@ def main(argv=None):
 
     def static_leg(the_scene, the_cam, n_frames, n_warm, in_flight, ref_frame, active=True):
         """n_frames launches of one pose on `in_flight` streams (1 = back to back), timed by the contract's harness.
-        Ranks with active=False take part in the barriers only.  -> seconds (max over ranks)."""
+        Ranks with active=False take part in the barriers only.  -> (seconds (max over ranks), check callable: the
+        frames just timed against the instrumented kernel's -- called after any HIP-event timing that should see the
+        GPU in the same state, the read-back idles it)."""
         if not active:
-            return timed(lambda: None, n_frames)
+            return timed(lambda: None, n_frames), lambda: None
         keep, lanes = make_lanes(in_flight, the_cam.width, the_cam.height)
         nxt, _ = round_robin(lanes)
 
@@ -452,11 +454,13 @@ def main(argv=None):
         for _ in range(n_warm):
             step()
         dt = timed(step, n_frames)
-        for st_, o_ in lanes[:min(in_flight, n_warm + n_frames)]:
-            if not np.array_equal(o_.cpu().numpy(), ref_frame):
-                raise SystemExit("bench.py: a timed static-pose leg produced a different frame than hmrm_render_stats")
-        del keep
-        return dt
+
+        def check():
+            for st_, o_ in lanes[:min(in_flight, n_warm + n_frames)]:
+                if not np.array_equal(o_.cpu().numpy(), ref_frame):
+                    raise SystemExit("bench.py: a timed static-pose leg produced a different frame than hmrm_render_stats")
+            keep.clear()
+        return dt, check
 
     def orbit_leg(the_wl, the_scene, n_frames, n_warm, in_flight, solo=False):
         """Frame k of the workload's 64-frame orbit on rank k mod world, n_frames timed per rank after n_warm untimed;
@@ -556,8 +560,9 @@ def main(argv=None):
         c = w.camera()
         fb, s_, _, _ = the_scene.render_stats(c)
         precondition(the_scene, c)
-        dt = static_leg(the_scene, c, n_frames, n_warm, 1, fb)
-        kms = the_scene.bench_kernel_ms(c, min(50, max(10, n_frames)))
+        dt, check = static_leg(the_scene, c, n_frames, n_warm, 1, fb)
+        kms = the_scene.bench_kernel_ms(c, min(50, max(10, n_frames)))  # (straight behind the timed launches: same clocks)
+        check()
         return {"workload": workload_text(w), "frames": n_frames, "ms_per_step": dt * 1e3 / n_frames, "kernel_ms": kms,
                 "value": int(s_.steps) * n_frames / dt, "unit": "ray-steps/s", "equivalent_steps": True,
                 "mrays_per_s": int(s_.rays) * n_frames / dt / 1e6, "ray_steps_per_frame": int(s_.steps),
@@ -582,15 +587,16 @@ def main(argv=None):
     extra = {}
     in_flight = max(1, min(args.frames_in_flight, 4))
     if not multi:
-        elapsed = static_leg(scene, cam, args.steps, args.warmup, in_flight, fb_ref)
+        elapsed, check_headline = static_leg(scene, cam, args.steps, args.warmup, in_flight, fb_ref)
         total_steps_timed = frame_steps * args.steps
         rays_timed = frame_rays * args.steps
         scaling = "weak"
         parallelism = "1 GPU, launches back to back on one stream" if in_flight == 1 else \
                       f"1 GPU, {in_flight} frames in flight on {in_flight} HIP streams"
     elif args.mode == "frames":
-        elapsed, total_steps_timed, check_headline = orbit_leg(wl, scene, args.steps, args.warmup, in_flight)
-        check_headline()
+        elapsed, total_steps_timed, check_orbit = orbit_leg(wl, scene, args.steps, args.warmup, in_flight)
+        check_orbit()
+        check_headline = lambda: None  # noqa: E731
         rays_timed = frame_rays * args.steps * world
         scaling = "weak"
         parallelism = (f"{ORBIT_FRAMES}-frame orbit, frame k on GPU k mod {world} ({args.steps} frames per GPU), "
@@ -622,14 +628,18 @@ def main(argv=None):
         parallelism = f"cyclic {BAND_ROWS}-row bands over {world} GPUs + RCCL gather to rank 0"
         if rank == 0 and not np.array_equal(result["frame"].cpu().numpy(), fb_ref):
             raise SystemExit("bench.py: timed path produced a different frame than hmrm_render_stats")
+        check_headline = lambda: None  # noqa: E731
 
     # dominant kernel: mean launch duration by HIP events on the launch stream (full frame, static pose, back to back)
     kernel_ms = scene.bench_kernel_ms(cam, 50) if rank == 0 else None
+    # correctness of what was just timed, against the instrumented kernel (another instantiation, host read-back path)
+    check_headline()
 
     secondary = {}
     if not args.no_secondary and not multi:
         # ---- three frames in flight (a throughput mode for sequences of independent frames, hmap.cpp:1131-1144)
-        dt3 = static_leg(scene, cam, args.steps, 50 + args.warmup, 3, fb_ref)
+        dt3, check3 = static_leg(scene, cam, args.steps, 50 + args.warmup, 3, fb_ref)
+        check3()
         secondary["frames_in_flight"] = {"streams": 3, "ms_per_step": dt3 * 1e3 / args.steps,
                                          "value": frame_steps * args.steps / dt3,
                                          "note": "same K frames round-robin over 3 HIP streams; not the operating point of `roofline`"}
@@ -669,7 +679,7 @@ def main(argv=None):
         # ---- the kernel that executes every one of the reference's loads, on the headline frame: the one kernel
         # SURVEY 8(d)'s algorithmic-bytes fraction is defined for
         def literal():
-            scene.bench_kernel_ms(cam, 1)
+            scene.bench_kernel_ms(cam, 2)
             return scene.bench_kernel_ms(cam, 3)
         lit_ms = with_kernel("simple", literal)
         lit_pmc, lit_prov = _pmc_from_profiles(wl.name + "_literal", hmrm.kernel_src_sha())
@@ -736,8 +746,10 @@ def main(argv=None):
             c3 = w3.camera()
             fb3, st3, _, _ = scene.render_stats(c3)
             precondition(scene, c3)
-            dt_all = static_leg(scene, c3, args.steps, args.warmup, 1, fb3)
-            dt_one = static_leg(scene, c3, args.steps, args.warmup, 1, fb3, active=rank == 0)
+            dt_all, check_all = static_leg(scene, c3, args.steps, args.warmup, 1, fb3)
+            check_all()
+            dt_one, check_one = static_leg(scene, c3, args.steps, args.warmup, 1, fb3, active=rank == 0)
+            check_one()
             secondary["static_pose_replicas"] = {
                 "workload": workload_text(w3), "frames_per_gpu": args.steps, "ms_per_step": dt_all * 1e3 / args.steps,
                 "value": int(st3.steps) * args.steps * world / dt_all, "unit": "ray-steps/s", "scaling": "weak",

@@ -61,6 +61,10 @@ struct Knobs {
 	int min_level = -1;                  // HMRM_MIN_LEVEL (tools)
 	int finest_pause = -1;               // HMRM_FINEST_PAUSE (tools)
 	bool order_verbose = false;          // HMRM_ORDER_VERBOSE=1 (tools): report every calibration on stderr
+	int persist = 0;                     // HMRM_PERSIST=1 (experiment): full frames through the persistent-tile kernel
+	int persist_chunk = 8;               // HMRM_PERSIST_CHUNK: wave tiles per dequeue on the rows behind the marching ones
+	int persist_waves = 0;               // HMRM_PERSIST_WAVES: waves to launch (0 = every slot of the device)
+	int persist_single = -1;             // HMRM_PERSIST_SINGLE: grid rows handed out one wave tile at a time (-1 = the marching rows)
 	int seg_n = 0;                       // HMRM_TILE_SEGMENTS=b0:c0,b1:c1,.. (tools): tile-row pieces to start first, in this order
 	int seg_b[3] = {0, 0, 0}, seg_c[3] = {0, 0, 0};
 };
@@ -81,6 +85,10 @@ Knobs read_knobs() {
 	}
 	if (const char *s = getenv("HMRM_DIAG_ITERS")) k.diag_mode = atoi(s);
 	if (const char *s = getenv("HMRM_ORDER_VERBOSE")) k.order_verbose = s[0] == '1';
+	if (const char *s = getenv("HMRM_PERSIST")) k.persist = atoi(s);
+	if (const char *s = getenv("HMRM_PERSIST_CHUNK")) k.persist_chunk = std::max(1, atoi(s));
+	if (const char *s = getenv("HMRM_PERSIST_WAVES")) k.persist_waves = std::max(0, atoi(s));
+	if (const char *s = getenv("HMRM_PERSIST_SINGLE")) k.persist_single = atoi(s);
 	if (const char *s = getenv("HMRM_TILE_SEGMENTS")) {
 		int b = 0, c = 0, used = 0;
 		while (k.seg_n < 3 && sscanf(s, "%d:%d%n", &b, &c, &used) == 2 && b >= 0 && c > 0) {
@@ -158,6 +166,10 @@ struct StreamCtx {
 	unsigned long long capped_seen = 0; // value of [2] the host has already reported
 	// recorded behind every launch: what a recycled context waits for (the caller's stream handle may be gone by then)
 	hipEvent_t last_launch = nullptr;
+	// persistent-tile kernel: kHeadSets sets of queue heads, used in turn by the stream's launches (launch n zeroes the
+	// set launch n + kHeadSets / 2 will use: stream order keeps the three apart)
+	unsigned *d_heads = nullptr;
+	uint32_t persist_launches = 0;
 };
 
 // One slot of the asynchronous read-back ring (hmrm_render_begin/_wait/_release): a device frame
@@ -245,6 +257,7 @@ void destroy_ctx(StreamCtx *c) {
 	if (c->d_arena) (void)hipFree(c->d_arena);
 	if (c->h_arena) (void)hipHostFree(c->h_arena);
 	if (c->d_counters) (void)hipFree(c->d_counters);
+	if (c->d_heads) (void)hipFree(c->d_heads);
 	if (c->last_launch) (void)hipEventDestroy(c->last_launch);
 	delete c;
 }
@@ -471,7 +484,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
                  uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats) {
 	hmrm::RowMap rows_in_order = rows;
 	bool measure_now = false;
-	int tiles_y = 0, trial_now = -1;
+	int tiles_y = 0, trial_now = -1, rot_used = 0;
 	{
 		int tile_w = 1, tile_h = 1;
 		hmrm::render_tile_shape(&tile_w, &tile_h);
@@ -481,7 +494,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 		int nb = pieces ? s->knobs.seg_n : 0, b[3] = {s->knobs.seg_b[0], s->knobs.seg_b[1], s->knobs.seg_b[2]},
 		    c3[3] = {s->knobs.seg_c[0], s->knobs.seg_c[1], s->knobs.seg_c[2]};
 		// calibration (see plan_order_from_measurement): full frames of the production kernel only
-		const bool eligible = !pieces && !stats && s->knobs.tile_order && s->knobs.order_mode == 2 && s->knobs.kernel != 2 &&
+		const bool eligible = !pieces && !stats && s->knobs.tile_order && s->knobs.order_mode == 2 && s->knobs.kernel != 2 && !s->knobs.persist &&
 		                      rows.band_rows == 0 && rows.row_begin == 0 && rows.local_rows == f.screen_h && tiles_y >= 12 &&
 		                      tiles_y <= kMaxMeasRows && s->map_w < (1 << 24) && s->map_h < (1 << 24);
 		if (eligible) {
@@ -541,6 +554,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 			for (int k = 0; k < nb; ++k) { b[k] = slot->trials[use].b[k]; c3[k] = slot->trials[use].c[k]; }
 		}
 		hmrm::set_tile_order(&rows_in_order, tiles_y, rot, nb, b, c3);
+		rot_used = rot;
 	}
 	if (measure_now) {
 		if (!c->d_meas) {
@@ -563,6 +577,28 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 	if ((s->knobs.kernel == 2 || huge_side) && f.sampling == 0) { // (the literal loop only knows the reference's sampling)
 		HIP_TRY(hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters, d_steps,
 		                            d_entry, stats, c->stream));
+	} else if (s->knobs.persist && s->knobs.kernel == 0 && !stats && !measure_now && rows.band_rows == 0 && tiles_y >= 2) {
+		// experiment (HMRM_PERSIST=1): resident waves pull the wave tiles from a queue, in the rotation's order
+		constexpr int kHeadSets = 64;
+		constexpr size_t kSetWords = (size_t)hmrm::kPersistHeads * 32;
+		if (!c->d_heads) {
+			HIP_TRY(hipMalloc((void **)&c->d_heads, kHeadSets * kSetWords * sizeof(unsigned)));
+			HIP_TRY(hipMemsetAsync(c->d_heads, 0, kHeadSets * kSetWords * sizeof(unsigned), c->stream));
+		}
+		const uint32_t n = c->persist_launches++;
+		// the rotation starts at the first marching tile row and wraps: the tile rows in front of it come last
+		const int single = s->knobs.persist_single >= 0 ? s->knobs.persist_single : tiles_y - rot_used;
+		const hipError_t e = hmrm::launch_render_persist(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px, c->d_counters,
+		                                                 c->d_heads + (n % kHeadSets) * kSetWords,
+		                                                 c->d_heads + ((n + kHeadSets / 2) % kHeadSets) * kSetWords, single,
+		                                                 s->knobs.persist_chunk, s->knobs.persist_waves, c->stream);
+		if (e == hipErrorNotSupported) {
+			--c->persist_launches;
+			HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
+			                                 c->d_counters, d_steps, d_entry, stats, true, c->stream));
+		} else {
+			HIP_TRY(e);
+		}
 	} else {
 		const bool leap = s->knobs.kernel != 1;
 		HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,

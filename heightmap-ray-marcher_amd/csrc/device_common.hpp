@@ -249,12 +249,12 @@ __device__ __forceinline__ int frame_row_of(const RowMap &rows, int lrow) {
 	return rows.row_begin + lrow;
 }
 
-__device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap &rows, int tiles_y) {
+// Pixel of lane `lane` of wave `wave` of the workgroup-sized tile (tile_x, grid row gy).
+__device__ __forceinline__ PixelId pixel_of_tile_lane(const DevFrame &f, const RowMap &rows, int tiles_y, int tile_x, unsigned gy,
+                                                      int wave, int lane) {
 	// Grid of tiles: x = tile column (fastest, so workgroups still start row by row), y (+ z for
 	// frames taller than 32768 tile rows) = grid row; grid rows are handed to tile rows piece by piece so that the
 	// costliest tile rows start first (RowMap::seg_first / seg_delta).  Scalar work, no integer division per wave.
-	const int tile_x = (int)blockIdx.x;
-	const unsigned gy = blockIdx.z * 32768u + blockIdx.y;
 	const bool row_exists = gy < (unsigned)tiles_y; // (the last z-slab may be partly empty)
 	int delta = rows.seg_delta[0];
 #pragma unroll
@@ -264,12 +264,16 @@ __device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap
 	const int tile_y = (int)ty;
 	PixelId p;
 	p.tile_y = row_exists ? tile_y : -1;
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	p.px = tile_x * kTileW + (wave % kWavesX) * kWaveW + (lane % kWaveW);
 	p.lrow = tile_y * kTileH + (wave / kWavesX) * kWaveH + (lane / kWaveW);
 	p.py = frame_row_of(rows, p.lrow);
 	p.live = row_exists && p.px < f.screen_w && p.lrow < rows.local_rows && p.py < f.screen_h;
 	return p;
+}
+// ... of the launch's own workgroup (one workgroup per tile: blockIdx is the tile)
+__device__ __forceinline__ PixelId pixel_of_lane(const DevFrame &f, const RowMap &rows, int tiles_y) {
+	return pixel_of_tile_lane(f, rows, tiles_y, (int)blockIdx.x, blockIdx.z * 32768u + blockIdx.y, (int)(threadIdx.x >> 6),
+	                          (int)(threadIdx.x & 63));
 }
 
 // Wave-reduce and publish the per-launch counters {steps, hits, capped}.

@@ -153,22 +153,18 @@ __device__ TimelineRec *g_timeline = nullptr;
 #endif
 // SAMP: 0 nearest cell (the reference), 1 bilinear quality mode, 2 nearest cell with float thresholds
 // (`thr` then points at the float copy of the table).
+// One wave's 8 x 8 pixels: wave `wave` of the workgroup-sized tile (tile_x, grid row gy).  Returns the tile row rendered
+// (-1: the grid row does not exist).  Inlined into k_render_fast (one tile per workgroup, the tile is blockIdx) and
+// into k_render_persist (waves pull tiles from a queue).
 template <int PROJ, bool STATS, int GWM, bool LEAP, int SAMP>
-__global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR void k_render_fast(const DevFrame f, const RowMap rows,
-                                                     const double *__restrict__ thr,
-                                                     const uint32_t *__restrict__ cmap,
-                                                     uint32_t *__restrict__ out, int64_t out_stride_px,
-                                                     int tiles_y, StatsOut st) {
+__device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap &rows, const double *__restrict__ thr,
+                                                const uint32_t *__restrict__ cmap, uint32_t *__restrict__ out,
+                                                int64_t out_stride_px, int tiles_y, const StatsOut &st, int tile_x, unsigned gy,
+                                                int wave, int lane) {
 	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
 	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
 	const float *__restrict__ mip = BILINEAR ? f.mipbuf_bil : f.mipbuf; // the pyramid this sampling mode leaps on
-	const PixelId pid = pixel_of_lane(f, rows, tiles_y);
-#ifdef HMRM_TIMELINE
-	const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
-	// calibration launches only (RowMap::measure): when did this wave start
-	unsigned long long wave_t0 = 0;
-	if (!STATS && rows.measure) wave_t0 = __builtin_amdgcn_s_memrealtime();
+	const PixelId pid = pixel_of_tile_lane(f, rows, tiles_y, tile_x, gy, wave, lane);
 	LoopDiag<STATS> diag; // (empty unless STATS: leap_diag.hpp)
 	diag.start();
 	unsigned long long my_steps = 0;
@@ -551,11 +547,29 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 	}
 	publish_counters<STATS>(st, my_steps, my_hit, my_cap);
 	diag.publish(st, f);
-	if (!STATS && rows.measure && pid.tile_y >= 0 && (threadIdx.x & 63) == 0) {
+	return pid.tile_y;
+}
+
+template <int PROJ, bool STATS, int GWM, bool LEAP, int SAMP>
+__global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR void k_render_fast(const DevFrame f, const RowMap rows,
+                                                     const double *__restrict__ thr,
+                                                     const uint32_t *__restrict__ cmap,
+                                                     uint32_t *__restrict__ out, int64_t out_stride_px,
+                                                     int tiles_y, StatsOut st) {
+#ifdef HMRM_TIMELINE
+	const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+	// calibration launches only (RowMap::measure): when did this wave start
+	unsigned long long wave_t0 = 0;
+	if (!STATS && rows.measure) wave_t0 = __builtin_amdgcn_s_memrealtime();
+	const int tile_y = render_wave_tile<PROJ, STATS, GWM, LEAP, SAMP>(f, rows, thr, cmap, out, out_stride_px, tiles_y, st, (int)blockIdx.x,
+	                                                                  blockIdx.z * 32768u + blockIdx.y, (int)(threadIdx.x >> 6),
+	                                                                  (int)(threadIdx.x & 63));
+	if (!STATS && rows.measure && tile_y >= 0 && (threadIdx.x & 63) == 0) {
 		// record of a tile row: [0] start of its first workgroup (rows are handed out left to right), [1 + k] longest
 		// wave among the tile columns = k mod 32 (32 addresses per row: the atomics of a row's 2 x 480 waves spread out)
 		const unsigned long long took = __builtin_amdgcn_s_memrealtime() - wave_t0;
-		unsigned long long *rec = rows.measure + (size_t)pid.tile_y * kMeasureStride;
+		unsigned long long *rec = rows.measure + (size_t)tile_y * kMeasureStride;
 		if (blockIdx.x == 0 && threadIdx.x == 0) rec[0] = wave_t0;
 		atomicMax(&rec[1 + (blockIdx.x & 31u)], took);
 	}
@@ -567,6 +581,75 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 		g_timeline[wave] = TimelineRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), xcc, 0u};
 	}
 #endif
+}
+
+// ------------------------------------------------------------ persistent tiles ----
+// The same wave tiles, pulled from a queue by a grid of resident waves instead of dispatched one workgroup per tile
+// (are the dispatch floor of the miss-only waves -- an all-miss 4K frame takes 0.031 ms of dispatch -- and
+// the 4.6-of-8 residency recoverable?).  Work list = the wave tiles (two per workgroup-sized tile) in the launch order of
+// `rows`.  Chunk c of the list belongs to head c mod kPersistHeads; a wave takes chunks from the head of its XCD slot until
+// that head runs out, then from the other heads in turn; it exits when every head has run out (heads only grow: every
+// wave reaches that).  One returning atomic per dequeue, on 32 lines: a single word saturates at ~88 dequeues / us
+// (MI355X_MICROARCH.md), so marching rows (one wave tile per dequeue: a marching wave runs 20-60 us, handing several to one
+// wave would unbalance the launch) and rows that mostly miss (q.chunk per dequeue) are listed separately.
+struct PersistQueue {
+	unsigned *heads;      // kPersistHeads x 32 words, zero at launch
+	unsigned *heads_zero; // ... of a later launch of this stream: zeroed here
+	unsigned tiles_x;     // workgroup-sized tiles per grid row
+	unsigned magic;       // floor(2^32 / tiles_x) + 1: t / tiles_x == mulhi(t, magic) for t * tiles_x < 2^32
+	unsigned total;       // wave tiles of the launch
+	unsigned single;      // wave tiles handed out one per dequeue (the first rows of the launch order)
+	unsigned chunk;       // wave tiles per dequeue behind them
+	unsigned n_chunks;    // single + ceil((total - single) / chunk)
+};
+
+#ifndef HMRM_PERSIST_WAVES_PER_EU
+#define HMRM_PERSIST_WAVES_PER_EU 7
+#endif
+#define HMRM_PERSIST_ATTR __attribute__((amdgpu_waves_per_eu(HMRM_PERSIST_WAVES_PER_EU, HMRM_PERSIST_WAVES_PER_EU)))
+template <int PROJ, int GWM, int SAMP>
+__global__ __launch_bounds__(64) HMRM_PERSIST_ATTR void k_render_persist(const DevFrame f, const RowMap rows_arg, const double *__restrict__ thr,
+                                                       const uint32_t *__restrict__ cmap, uint32_t *__restrict__ out,
+                                                       int64_t out_stride_px, int tiles_y, StatsOut st, PersistQueue q) {
+	const int lane = (int)threadIdx.x;
+	RowMap rows = rows_arg;
+	rows.band_rows = 0; // (contiguous frames only, launch_render_persist: the band arithmetic folds away)
+	rows.measure = nullptr;
+	if (blockIdx.x == 0 && lane < kPersistHeads) q.heads_zero[lane * 32] = 0u;
+	unsigned xcc;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+	// workgroups go round-robin to the XCDs: (blockIdx.x >> 3) tells the workgroups of one XCD apart
+	const unsigned own = ((xcc & 7u) * (kPersistHeads / 8) + ((blockIdx.x >> 3) & (kPersistHeads / 8 - 1))) & (kPersistHeads - 1);
+	for (unsigned probe = 0; probe < (unsigned)kPersistHeads;) {
+		const unsigned h = (own + probe) & (kPersistHeads - 1);
+		unsigned k = 0;
+		if (lane == 0) k = __hip_atomic_fetch_add(&q.heads[h * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+		const unsigned long long c64 = (unsigned long long)k * kPersistHeads + h;
+		if (c64 >= q.n_chunks) { // this head has run out
+			++probe;
+			continue;
+		}
+		const unsigned c = (unsigned)c64;
+		unsigned w = c < q.single ? c : q.single + (c - q.single) * q.chunk;
+		unsigned cnt = c < q.single ? 1u : q.chunk;
+		cnt = cnt < q.total - w ? cnt : q.total - w;
+		unsigned t = w >> 1;
+		int wave = (int)(w & 1u);
+		unsigned gy = __umulhi(t, q.magic);
+		unsigned tx = t - gy * q.tiles_x;
+		for (unsigned j = 0; j < cnt; ++j) {
+			render_wave_tile<PROJ, false, GWM, true, SAMP>(f, rows, thr, cmap, out, out_stride_px, tiles_y, st, (int)tx, gy, wave, lane);
+			wave ^= 1;
+			if (wave == 0) {
+				++tx;
+				if (tx == q.tiles_x) {
+					tx = 0;
+					++gy;
+				}
+			}
+		}
+	}
 }
 
 // ---------------------------------------------------------------- pyramid ----
@@ -805,6 +888,71 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 	return hipGetLastError();
+}
+
+template <int PROJ, int GWM>
+static hipError_t launch_persist_samp(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
+                                      uint32_t *d_out, int64_t out_stride_px, int tiles_y, StatsOut st, const PersistQueue &q,
+                                      int waves, hipStream_t stream) {
+	auto go = [&](auto kernel) -> hipError_t {
+		static int slots = 0; // waves the device holds at once for this instantiation
+		if (slots == 0) {
+			int dev = 0, cus = 0, per_cu = 0;
+			hipError_t e = hipGetDevice(&dev);
+			if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+			if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0);
+			if (e != hipSuccess) return e;
+			slots = cus * per_cu;
+		}
+		int n = waves > 0 ? waves : slots;
+		if ((unsigned)n > q.n_chunks) n = (int)q.n_chunks;
+		hipLaunchKernelGGL(kernel, dim3((unsigned)(n < 1 ? 1 : n)), dim3(64), 0, stream, f, rows, d_thr, d_cmap, d_out, out_stride_px,
+		                   tiles_y, st, q);
+		return hipGetLastError();
+	};
+	if (f.sampling == 1) return go(k_render_persist<PROJ, GWM, 1>);
+	if (f.sampling == 2) return go(k_render_persist<PROJ, GWM, 2>);
+	return go(k_render_persist<PROJ, GWM, 0>);
+}
+
+template <int PROJ>
+static hipError_t launch_persist_gwm(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
+                                     uint32_t *d_out, int64_t out_stride_px, int tiles_y, StatsOut st, const PersistQueue &q,
+                                     int waves, hipStream_t stream) {
+	switch (f.grid_mode) {
+	case 0: return launch_persist_samp<PROJ, 0>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
+	case 1: return launch_persist_samp<PROJ, 1>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
+	default: return launch_persist_samp<PROJ, 2>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
+	}
+}
+
+hipError_t launch_render_persist(const DevFrame &f, const RowMap &rows, const double *d_thr_f64, const float *d_thr32,
+                                 const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
+                                 unsigned long long *d_counters, unsigned *heads, unsigned *heads_zero, int single_rows,
+                                 int chunk, int waves, hipStream_t stream) {
+	static_assert(kWavesX == 1 && kWavesY == 2, "k_render_persist decodes wave tiles of 1 x 2-wave workgroup tiles");
+	const double *d_thr = f.sampling == 2 ? reinterpret_cast<const double *>(d_thr32) : d_thr_f64;
+	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
+	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
+	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
+	// mulhi(t, magic) == t / tiles_x needs t * tiles_x < 2^32 for every tile index t
+	if ((uint64_t)tiles_x * tiles_x * tiles_y >= ((uint64_t)1 << 32) || chunk < 1 || rows.band_rows > 0) return hipErrorNotSupported;
+	PersistQueue q;
+	q.heads = heads;
+	q.heads_zero = heads_zero;
+	q.tiles_x = (unsigned)tiles_x;
+	q.magic = (unsigned)((((uint64_t)1 << 32) / (uint64_t)tiles_x) + 1);
+	q.total = 2u * (unsigned)tiles_x * (unsigned)tiles_y;
+	const int sr = single_rows < 0 ? 0 : (single_rows > tiles_y ? tiles_y : single_rows);
+	q.single = 2u * (unsigned)tiles_x * (unsigned)sr;
+	q.chunk = (unsigned)chunk;
+	q.n_chunks = q.single + (q.total - q.single + q.chunk - 1) / q.chunk;
+	StatsOut st{d_counters, nullptr, nullptr};
+	switch (f.projection) {
+	case 1: return launch_persist_gwm<1>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
+	case 2: return launch_persist_gwm<2>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
+	default: return launch_persist_gwm<3>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
+	}
 }
 
 void render_tile_shape(int *tile_w, int *tile_h) {

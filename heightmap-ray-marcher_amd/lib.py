@@ -203,7 +203,8 @@ def set_device(i: int):
 
 # The library reads its environment knobs once per scene.  Tests and tools flip them
 # on live scenes, so the Python wrappers re-read them when one changed since the scene last looked.
-_ENV_KNOBS = ("HMRM_KERNEL", "HMRM_STEP_CAP", "HMRM_TILE_ORDER", "HMRM_DIAG_ITERS", "HMRM_MIN_LEVEL", "HMRM_FINEST_PAUSE", "HMRM_TILE_SEGMENTS", "HMRM_ORDER_VERBOSE")
+_ENV_KNOBS = ("HMRM_KERNEL", "HMRM_STEP_CAP", "HMRM_TILE_ORDER", "HMRM_DIAG_ITERS", "HMRM_MIN_LEVEL", "HMRM_FINEST_PAUSE", "HMRM_TILE_SEGMENTS", "HMRM_ORDER_VERBOSE",
+              "HMRM_PERSIST", "HMRM_PERSIST_CHUNK", "HMRM_PERSIST_WAVES", "HMRM_PERSIST_SINGLE")
 
 
 def _env_snapshot():

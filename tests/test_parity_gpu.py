@@ -646,6 +646,8 @@ def test_one_frame_over_several_scenes(gpu, oracle):
         host = torch.full((cam.height, stride), 9, dtype=torch.uint8)
         if pinned:
             host = host.pin_memory()
+        for sc in many[:3]:
+            sc._sync_env()  # (the step cap of the block above is gone: the raw C call below does not re-read the knobs)
         arr = (ctypes.c_void_p * 3)(*[sc._h for sc in many[:3]])
         rc = gpu.lib.lib.hmrm_render_multi(arr, 3, ctypes.byref(cam), ctypes.c_void_p(host.data_ptr()), stride)
         assert rc == 0, gpu.last_error()

@@ -2,6 +2,7 @@
 # usage: tools/ab_build.sh "<flags A>" "<flags B>" [workloads...] -- interleaved A/B of two builds of libhmrm.so on the GPU box:
 # kernel ms of the production kernel per workload (tools/variants_bench.py) and the C3 row strips (tools/strip_time.py)
 set -e
+trap 'bash "$(dirname "$0")/sweep_build.sh" ""' EXIT
 A="$1"; B="$2"; shift 2
 WLS="${@:-C3 C5 C2 C4}"
 for round in 1 2; do
@@ -12,4 +13,3 @@ for round in 1 2; do
     timeout -k 10 100 python tools/strip_time.py 2>&1 | grep -E "784.. 800|0..2160| 800..2160"
   done
 done
-bash "$(dirname "$0")/sweep_build.sh" ""

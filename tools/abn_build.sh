@@ -3,6 +3,8 @@
 # libhmrm.so on the GPU box: kernel ms of the production kernel per workload (tools/variants_bench.py) and the heavy C3 row
 # strip (tools/strip_time.py).  Restores the default build at the end.
 set -e
+# (a failing or timed-out variant run must not leave libhmrm.so built with experimental flags: ADVICE r03)
+trap 'bash "$(dirname "$0")/sweep_build.sh" ""' EXIT
 WLS="${WLS:-C3 C5 C2 C4}"
 for round in $(seq 1 "${ROUNDS:-2}"); do
   for flags in "$@"; do
@@ -12,4 +14,3 @@ for round in $(seq 1 "${ROUNDS:-2}"); do
     if [ -z "$NO_STRIPS" ]; then timeout -k 10 100 python tools/strip_time.py 2>&1 | grep -E "784.. 800|   0..2160"; fi
   done
 done
-bash "$(dirname "$0")/sweep_build.sh" ""
