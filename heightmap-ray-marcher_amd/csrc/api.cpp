@@ -150,6 +150,7 @@ struct FrameSlot {
 // share a table or a counter (hmrm_render_rows_device takes the caller's stream).
 struct StreamCtx {
 	hipStream_t stream = nullptr;
+	bool scene_owned = false; // the scene's own stream or one of its launch lanes: never recycled
 	uint64_t stamp = 0;
 	FrameSlot slots[kFrameSlots];
 	// table storage of all slots: one device and one pinned allocation per context (a slot's first use would
@@ -176,6 +177,7 @@ struct StreamCtx {
 // the kernel writes, a pinned host frame the copy engine fills while the next kernel runs, and the
 // events that order the two streams.
 struct RingFrame {
+	StreamCtx *ctx = nullptr;   // launch state of the lane the frame's kernel ran on (its capped-ray counter)
 	uint32_t *d_frame = nullptr;
 	uint8_t *h_frame = nullptr; // pinned
 	unsigned long long *h_capped = nullptr; // pinned: the stream's cumulative capped-ray counter after this frame
@@ -185,6 +187,18 @@ struct RingFrame {
 	bool busy = false;
 };
 constexpr int kMaxRing = 64;
+// Launch lanes: the ticketed entry points (hmrm_render_begin, hmrm_render_device_begin) send consecutive frames to
+// kLanes scene-owned streams in turn, so that one launch's tail (a few long waves) overlaps the next launch's start
+// without the caller managing streams -- what bench.py's `frames_in_flight` block does by hand (C2: 0.064 -> 0.045 ms per
+// frame, profiles/r03_experiments.txt section 6).
+constexpr int kLanes = 3;
+// A frame rendered into the caller's DEVICE memory through a lane (hmrm_render_device_begin / _wait).
+struct DevTicket {
+	StreamCtx *ctx = nullptr;
+	hipEvent_t done = nullptr;
+	unsigned long long *h_capped = nullptr; // pinned: the lane's cumulative capped-ray counter after this frame
+	bool busy = false;
+};
 
 struct hmrm_scene {
 	int device = 0;
@@ -208,7 +222,10 @@ struct hmrm_scene {
 	float *plane(float *buf, int l) const { return buf + ((size_t)l << mip_plane_shift); }
 	hipStream_t stream = nullptr; // the scene's own stream (hmrm_render, updates)
 	hipStream_t copy_stream = nullptr; // device-to-host copies of the asynchronous ring
+	hipStream_t lanes[kLanes] = {};    // launch lanes of the ticketed entry points (created on first use)
+	uint32_t lane_next = 0;
 	std::vector<RingFrame *> ring;
+	std::vector<DevTicket *> dev_tickets;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	unsigned long long *d_maxkey = nullptr; // UpdateHeightmap's max(thr) reduction
 	// scratch of the host-memory entry points (hmrm_render*, one caller at a time)
@@ -272,9 +289,10 @@ int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 			return HMRM_OK;
 		}
 	if ((int)s->ctxs.size() >= kMaxStreamCtx) {
-		size_t victim = 1; // (never the scene's own stream, entry 0)
-		for (size_t i = 2; i < s->ctxs.size(); ++i)
-			if (s->ctxs[i]->stamp < s->ctxs[victim]->stamp) victim = i;
+		size_t victim = 0; // (never the scene's own stream -- entry 0 -- or one of its launch lanes)
+		for (size_t i = 1; i < s->ctxs.size(); ++i)
+			if (!s->ctxs[i]->scene_owned && (victim == 0 || s->ctxs[i]->stamp < s->ctxs[victim]->stamp)) victim = i;
+		if (victim == 0) return fail(HMRM_E_ARG, "too many streams");
 		// its kernels may still read the tables / counters about to be freed.  The stream belongs to the caller and
 		// may have been destroyed since (no call may name it any more): wait on the context's own event instead
 		(void)hipEventSynchronize(s->ctxs[victim]->last_launch);
@@ -284,6 +302,8 @@ int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 	StreamCtx *c = new (std::nothrow) StreamCtx();
 	if (!c) return fail(HMRM_E_ARG, "out of memory");
 	c->stream = stream;
+	c->scene_owned = stream == s->stream;
+	for (hipStream_t lane : s->lanes) c->scene_owned = c->scene_owned || (lane && stream == lane);
 	c->stamp = ++s->clock;
 	hipError_t e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_launch, hipEventDisableTiming);
@@ -611,8 +631,8 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 		slot->meas_rows = tiles_y;
 		slot->trial_in_flight = trial_now;
 	}
-	// (only streams other than the scene's own can be recycled, ctx_for)
-	if (c->stream != s->stream) HIP_TRY(hipEventRecord(c->last_launch, c->stream));
+	// (only streams other than the scene's own ones can be recycled, ctx_for)
+	if (!c->scene_owned) HIP_TRY(hipEventRecord(c->last_launch, c->stream));
 	return HMRM_OK;
 }
 
@@ -632,6 +652,13 @@ bool mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_w, int32_t *mip_h, in
 	*plane_shift = 0;
 	while (((size_t)1 << *plane_shift) < (size_t)hmrm::mip_index(mip_w[0] - 1, mip_h[0] - 1, *mip_row) + 1) ++*plane_shift;
 	return ((uint64_t)(hmrm::kMipLevels + 1) << *plane_shift) <= ((uint64_t)1 << 30);
+}
+
+// The launch state of the next lane in turn (lanes are created on first use; call with s->mu held).
+int next_lane(hmrm_scene *s, StreamCtx **out) {
+	const uint32_t i = s->lane_next++ % kLanes;
+	if (!s->lanes[i]) HIP_TRY(hipStreamCreateWithFlags(&s->lanes[i], hipStreamNonBlocking));
+	return ctx_for(s, s->lanes[i], out);
 }
 
 int ensure_frame(hmrm_scene *s, size_t px) {
@@ -822,8 +849,8 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (!s) return;
 	(void)hipSetDevice(s->device);
 	for (StreamCtx *c : s->ctxs) {
-		// (a caller's stream may already be gone: only the scene's own stream is drained)
-		if (c->stream == s->stream && s->stream) (void)hipStreamSynchronize(s->stream);
+		// (a caller's stream may already be gone: only the scene's own streams are drained)
+		if (c->scene_owned && c->stream) (void)hipStreamSynchronize(c->stream);
 		destroy_ctx(c);
 	}
 	s->ctxs.clear();
@@ -837,6 +864,17 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 		delete r;
 	}
 	s->ring.clear();
+	for (DevTicket *t : s->dev_tickets) {
+		if (t->done) (void)hipEventDestroy(t->done);
+		if (t->h_capped) (void)hipHostFree(t->h_capped);
+		delete t;
+	}
+	s->dev_tickets.clear();
+	for (hipStream_t &lane : s->lanes)
+		if (lane) {
+			(void)hipStreamDestroy(lane);
+			lane = nullptr;
+		}
 	if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
 	if (s->d_rgb) (void)hipFree(s->d_rgb);
 	if (s->d_cmap) (void)hipFree(s->d_cmap);
@@ -1201,13 +1239,14 @@ int hmrm_render_begin(const hmrm_scene *scene, const hmrm_camera *cam, int32_t *
 		r->px = W * H;
 	}
 	StreamCtx *c = nullptr;
-	if ((rc = ctx_for(s, s->stream, &c))) return rc;
+	if ((rc = next_lane(s, &c))) return rc;
 	hmrm::DevFrame f;
 	FrameSlot *slot = nullptr;
 	if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
 	hmrm::RowMap rows{0, cam->height, 0, 0, 1, {}, {}, nullptr};
 	if ((rc = launch_frame(s, c, f, slot, rows, r->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;
-	HIP_TRY(hipEventRecord(r->kernel_done, s->stream));
+	r->ctx = c;
+	HIP_TRY(hipEventRecord(r->kernel_done, c->stream));
 	HIP_TRY(hipStreamWaitEvent(s->copy_stream, r->kernel_done, 0));
 	HIP_TRY(hipMemcpyAsync(r->h_frame, r->d_frame, W * H * 4, hipMemcpyDeviceToHost, s->copy_stream));
 	HIP_TRY(hipMemcpyAsync(r->h_capped, c->d_counters + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -1235,11 +1274,9 @@ int hmrm_render_wait(const hmrm_scene *scene, int32_t ticket, const uint8_t **rg
 	*rgba = r->h_frame;
 	if (stride_bytes) *stride_bytes = (size_t)r->width * 4;
 	std::lock_guard<std::mutex> lk(s->mu);
-	StreamCtx *c = nullptr;
-	const int rc = ctx_for(s, s->stream, &c);
-	if (rc) return rc;
-	// the counter is cumulative over the stream's launches: later frames may already be in it, so a
-	// capped ray is reported with the first frame waited for after it happened
+	StreamCtx *c = r->ctx;
+	// the counter is cumulative over the lane's launches: later frames may already be in it, so a
+	// capped ray is reported with the first frame of the lane waited for after it happened
 	if (*r->h_capped > c->capped_seen) {
 		const unsigned long long n = *r->h_capped - c->capped_seen;
 		c->capped_seen = *r->h_capped;
@@ -1258,6 +1295,76 @@ void hmrm_render_release(const hmrm_scene *scene, int32_t ticket) {
 	(void)hipSetDevice(s->device);
 	(void)hipEventSynchronize(r->copy_done); // never hand a slot back while the copy engine writes it
 	r->busy = false;
+}
+
+// ---- frames into device memory through the launch lanes ----
+int hmrm_render_device_begin(const hmrm_scene *scene, const hmrm_camera *cam, void *d_rgba, size_t stride_bytes, int32_t *ticket) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
+	int rc = check_camera(cam);
+	if (rc) return rc;
+	if (!s || !d_rgba || !ticket) return fail(HMRM_E_ARG, "NULL argument");
+	*ticket = -1;
+	if (stride_bytes < (size_t)cam->width * 4 || (stride_bytes & 3) || stride_bytes / 4 > 0x7fffffffu)
+		return fail(HMRM_E_ARG, "stride_bytes must be >= width*4, a multiple of 4 and below 2^33");
+	HIP_TRY(hipSetDevice(s->device));
+	std::lock_guard<std::mutex> lk(s->mu);
+	int idx = -1;
+	for (size_t i = 0; i < s->dev_tickets.size(); ++i)
+		if (!s->dev_tickets[i]->busy) {
+			idx = (int)i;
+			break;
+		}
+	if (idx < 0) {
+		if ((int)s->dev_tickets.size() >= kMaxRing) return fail(HMRM_E_ARG, "hmrm_render_device_begin: 64 frames in flight (wait for one)");
+		DevTicket *t = new (std::nothrow) DevTicket();
+		if (!t) return fail(HMRM_E_ARG, "out of memory");
+		hipError_t e = hipEventCreateWithFlags(&t->done, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipHostMalloc((void **)&t->h_capped, sizeof(unsigned long long), hipHostMallocDefault);
+		if (e != hipSuccess) {
+			if (t->done) (void)hipEventDestroy(t->done);
+			delete t;
+			return fail(HMRM_E_DEVICE, std::string("hmrm_render_device_begin: ") + hipGetErrorString(e));
+		}
+		s->dev_tickets.push_back(t);
+		idx = (int)s->dev_tickets.size() - 1;
+	}
+	DevTicket *t = s->dev_tickets[(size_t)idx];
+	StreamCtx *c = nullptr;
+	if ((rc = next_lane(s, &c))) return rc;
+	hmrm::DevFrame f;
+	FrameSlot *slot = nullptr;
+	if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
+	hmrm::RowMap rows{0, cam->height, 0, 0, 1, {}, {}, nullptr};
+	if ((rc = launch_frame(s, c, f, slot, rows, (uint32_t *)d_rgba, (int64_t)(stride_bytes / 4), nullptr, nullptr, false))) return rc;
+	HIP_TRY(hipMemcpyAsync(t->h_capped, c->d_counters + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipEventRecord(t->done, c->stream));
+	t->ctx = c;
+	t->busy = true;
+	*ticket = idx;
+	return HMRM_OK;
+}
+
+int hmrm_render_device_wait(const hmrm_scene *scene, int32_t ticket) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
+	if (!s) return fail(HMRM_E_ARG, "NULL argument");
+	DevTicket *t = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(s->mu);
+		if (ticket < 0 || ticket >= (int)s->dev_tickets.size() || !s->dev_tickets[(size_t)ticket]->busy)
+			return fail(HMRM_E_ARG, "hmrm_render_device_wait: no such frame in flight");
+		t = s->dev_tickets[(size_t)ticket];
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipEventSynchronize(t->done)); // (outside the lock: other threads may begin frames meanwhile)
+	std::lock_guard<std::mutex> lk(s->mu);
+	t->busy = false;
+	StreamCtx *c = t->ctx;
+	if (*t->h_capped > c->capped_seen) {
+		const unsigned long long n = *t->h_capped - c->capped_seen;
+		c->capped_seen = *t->h_capped;
+		return noterm(n);
+	}
+	return HMRM_OK;
 }
 
 double hmrm_last_kernel_ms(void) { return g_last_kernel_ms; }

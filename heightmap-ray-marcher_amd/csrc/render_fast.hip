@@ -86,6 +86,27 @@ constexpr bool kAdaptive = kAdaptAfter > 0;
 #endif
 constexpr bool kEarlyLoad = HMRM_EARLY_LOAD != 0;
 
+// HMRM_GIVEUP (default 4; 0 = off): back-off of a ray whose attempts keep being refused at the FINEST level because it is
+// below that window's maximum (white-noise heights, needles on a plateau: every 4-cell window holds a tall cell, so such
+// a ray cannot jump until it hits -- and each refused attempt costs about as much as the group of real steps it delays).
+// The j-th consecutive refusal is followed by finest_pause + 2^(j-1) - 1 groups (j capped at HMRM_GIVEUP: + 0, 1, 3, 7),
+// so a ray that can never jump again spends a vanishing share of its trips on attempts while one that is refused a
+// few times (skimming a ridge) tries again at most twice as late as it would have.  A successful jump resets the count.
+// Performance only (profiles/r04_content.txt: white noise 1.06 -> x of the plain groups).
+#ifndef HMRM_GIVEUP
+#define HMRM_GIVEUP 4
+#endif
+constexpr int kGiveUp = HMRM_GIVEUP;
+// HMRM_WAVE_GIVEUP (default 8; 0 = off): the same at the level of the wave, where the cost is -- a wave executes the attempt
+// block whenever ANY of its lanes attempts, so lanes backing off one by one save little.  After HMRM_WAVE_GIVEUP trips in a
+// row in which lanes attempted and none jumped, nobody in the wave attempts for 4, 8, .. 64 trips (doubling while that keeps
+// happening; one successful jump resets it): on content that admits no jumps the kernel then runs the plain groups at the
+// plain groups' speed.  Wave-uniform state (scalar registers).  Performance only.
+#ifndef HMRM_WAVE_GIVEUP
+#define HMRM_WAVE_GIVEUP 8
+#endif
+constexpr int kWaveGiveUp = HMRM_WAVE_GIVEUP;
+
 // ---- bilinear quality mode (HMRM_BILINEAR; a build-side addition, not in the reference) ----
 // Same definition, operation for operation, as oracle/hmrm_oracle.c "bilinear quality mode":
 // values sit at cell centres; u = q - 0.5, t = u - floor(u), neighbours clamp(floor(u)) and
@@ -216,6 +237,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 					lev = (l >= f.min_level && lateral <= (double)((win_strides(l) - 1) << mip_stride_shift(l))) ? l : lev;
 			}
 			int cooldown = 0, fails = 0;
+			int refused_fine = 0; // consecutive height refusals at the finest level (kGiveUp)
 			int jumps = 0; // successful jumps so far (kAdaptive)
 			Axis ax, ay, az;
 			ax.key = ay.key = az.key = 0xfffffffeu; // never matches: forces the first refresh
@@ -231,13 +253,15 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 			// branch any of its lanes takes, and exec-mask juggling per `if` costs as much as
 			// the arithmetic it guards.  Values are computed for all lanes and selected.
 			bool done = entry_nan;
+			int w_state = 0; // (kWaveGiveUp; wave-uniform, one scalar register: pause | streak << 8 | doublings << 12)
 			while (!done) {
 				bool skip_group = false;
 				diag.begin_trip();
 				// ---------------------------------------------------------- leap
 				if (LEAP) {
-					const bool attempt = cooldown == 0;
-					cooldown -= attempt ? 0 : 1;
+					const bool attempt = kWaveGiveUp > 0 ? (cooldown == 0 && (w_state & 0xff) == 0) : cooldown == 0;
+					cooldown -= kWaveGiveUp > 0 ? (cooldown > 0 ? 1 : 0) : (attempt ? 0 : 1);
+					bool jumped = false;
 					if (attempt) {
 						diag.on_attempt();
 						// Order of the block (HMRM_EARLY_LOAD): the window look-up depends on the position and the level only, so
@@ -401,12 +425,29 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						const int fails_before = fails;
 						lev = hl ? finer : (go_up ? coarser : lev);
 						fails = (crossed | (hl & ok)) ? 0 : fails + (other ? 1 : 0);
-						cooldown = (hl & !ok & at_finest) ? f.finest_pause : (other ? (fails_before < 3 ? fails_before : 3) : 0);
+						const bool refused_here = hl & !ok & at_finest;
+						int fine_pause = f.finest_pause;
+						if (kGiveUp > 0) {
+							fine_pause += (1 << refused_fine) - 1; // (the count before this refusal: 0, 1, 3, 7 extra groups)
+							refused_fine = ok ? 0 : (refused_here && refused_fine < kGiveUp - 1 ? refused_fine + 1 : refused_fine);
+						}
+						cooldown = refused_here ? fine_pause : (other ? (fails_before < 3 ? fails_before : 3) : 0);
 						// retry one level down without marching; after a jump look at the next window straight
 						// away -- unless the jump stopped at a binade boundary: only real steps cross it,
 						// another attempt here would just fail
 						// (kCross: the jump's last step has crossed it)
 						skip_group = (hl & !ok & !at_finest) | (ok & (kCross | !binade_bound));
+						jumped = ok;
+					}
+					if (kWaveGiveUp > 0) {
+						const bool any_attempt = __builtin_amdgcn_ballot_w64(attempt) != 0ull;
+						const bool any_jump = __builtin_amdgcn_ballot_w64(jumped) != 0ull;
+						w_state -= (w_state & 0xff) ? 1 : 0;
+						w_state = any_jump ? (w_state & 0xff) : w_state + (any_attempt ? 0x100 : 0);
+						if (((w_state >> 8) & 0xf) >= kWaveGiveUp) {
+							const int k = w_state >> 12;
+							w_state = ((k < 4 ? k + 1 : k) << 12) | (4 << k);
+						}
 					}
 				}
 				diag.on_trip(f, LEAP, skip_group);
@@ -588,8 +629,8 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 // (are the dispatch floor of the miss-only waves -- an all-miss 4K frame takes 0.031 ms of dispatch -- and
 // the 4.6-of-8 residency recoverable?).  Work list = the wave tiles (two per workgroup-sized tile) in the launch order of
 // `rows`.  Chunk c of the list belongs to head c mod kPersistHeads; a wave takes chunks from the head of its XCD slot until
-// that head runs out, then from the other heads in turn; it exits when every head has run out (heads only grow: every
-// wave reaches that).  One returning atomic per dequeue, on 32 lines: a single word saturates at ~88 dequeues / us
+// that head runs out, then from the next head that has any left (one load of all the heads tells); it exits when that load
+// shows every head run out (heads only grow: every wave reaches that).  One returning atomic per dequeue, on 32 lines: a single word saturates at ~88 dequeues / us
 // (MI355X_MICROARCH.md), so marching rows (one wave tile per dequeue: a marching wave runs 20-60 us, handing several to one
 // wave would unbalance the launch) and rows that mostly miss (q.chunk per dequeue) are listed separately.
 struct PersistQueue {
@@ -603,10 +644,14 @@ struct PersistQueue {
 	unsigned n_chunks;    // single + ceil((total - single) / chunk)
 };
 
-#ifndef HMRM_PERSIST_WAVES_PER_EU
-#define HMRM_PERSIST_WAVES_PER_EU 7
-#endif
+// (the tile loop keeps per-frame values in registers across tiles: 89 VGPRs = 5 waves per SIMD where the one-tile kernel
+// has 62 = 8; forcing 6 or 7 with HMRM_PERSIST_WAVES_PER_EU spills and was slower, profiles/r04_experiments.txt)
+#if defined(HMRM_PERSIST_WAVES_PER_EU) && HMRM_PERSIST_WAVES_PER_EU > 0
 #define HMRM_PERSIST_ATTR __attribute__((amdgpu_waves_per_eu(HMRM_PERSIST_WAVES_PER_EU, HMRM_PERSIST_WAVES_PER_EU)))
+#else
+#define HMRM_PERSIST_ATTR
+#endif
+static_assert(kPersistHeads == 32, "k_render_persist keeps the heads' state in a 32-bit lane mask");
 template <int PROJ, int GWM, int SAMP>
 __global__ __launch_bounds__(64) HMRM_PERSIST_ATTR void k_render_persist(const DevFrame f, const RowMap rows_arg, const double *__restrict__ thr,
                                                        const uint32_t *__restrict__ cmap, uint32_t *__restrict__ out,
@@ -619,15 +664,24 @@ __global__ __launch_bounds__(64) HMRM_PERSIST_ATTR void k_render_persist(const D
 	unsigned xcc;
 	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 	// workgroups go round-robin to the XCDs: (blockIdx.x >> 3) tells the workgroups of one XCD apart
-	const unsigned own = ((xcc & 7u) * (kPersistHeads / 8) + ((blockIdx.x >> 3) & (kPersistHeads / 8 - 1))) & (kPersistHeads - 1);
-	for (unsigned probe = 0; probe < (unsigned)kPersistHeads;) {
-		const unsigned h = (own + probe) & (kPersistHeads - 1);
+	unsigned h = ((xcc & 7u) * (kPersistHeads / 8) + ((blockIdx.x >> 3) & (kPersistHeads / 8 - 1))) & (kPersistHeads - 1);
+	for (;;) {
 		unsigned k = 0;
 		if (lane == 0) k = __hip_atomic_fetch_add(&q.heads[h * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
 		const unsigned long long c64 = (unsigned long long)k * kPersistHeads + h;
-		if (c64 >= q.n_chunks) { // this head has run out
-			++probe;
+		if (c64 >= q.n_chunks) {
+			// This head has run out.  ONE load per lane reads all the heads (an atomic probe of each in turn costs a
+			// microsecond apiece under contention: 32 of them per wave at the end of a launch were most of its time);
+			// heads only grow, so "every head has run out" can be believed -- the wave is done -- and a head seen with
+			// work left is only a hint: its dequeue above decides.  Next: the first such head behind this one.
+			unsigned v = 0xffffffffu;
+			if (lane < kPersistHeads) v = __hip_atomic_load(&q.heads[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const bool has = lane < kPersistHeads && (unsigned long long)v * kPersistHeads + (unsigned)lane < q.n_chunks;
+			const unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(has);
+			if (mask == 0u) break;
+			const unsigned rot = (mask >> h) | (h ? mask << (32u - h) : 0u); // bit j = head (h + j) mod 32
+			h = (h + (unsigned)__builtin_ctz(rot)) & (kPersistHeads - 1);
 			continue;
 		}
 		const unsigned c = (unsigned)c64;

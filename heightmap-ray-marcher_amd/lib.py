@@ -126,6 +126,8 @@ def _load():
         "hmrm_render_begin": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(i32)]),
         "hmrm_render_wait": (C.c_int, [vp, i32, C.POINTER(u8p), C.POINTER(C.c_size_t)]),
         "hmrm_render_release": (None, [vp, i32]),
+        "hmrm_render_device_begin": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(i32)]),
+        "hmrm_render_device_wait": (C.c_int, [vp, i32]),
         "hmrm_config_create": (vp, []),
         "hmrm_config_destroy": (None, [vp]),
         "hmrm_config_consume_file": (C.c_int, [vp, C.c_char_p]),
@@ -311,6 +313,16 @@ class Scene:
 
     def render_release(self, ticket: int):
         lib.hmrm_render_release(self._h, ticket)
+
+    def render_device_begin(self, cam: Camera, d_ptr: int, stride_bytes: int) -> int:
+        """Launch a frame into device memory on the next of the scene's launch streams -> ticket."""
+        self._sync_env()
+        t = C.c_int32()
+        _check(lib.hmrm_render_device_begin(self._h, C.byref(cam), C.c_void_p(d_ptr), stride_bytes, C.byref(t)))
+        return int(t.value)
+
+    def render_device_wait(self, ticket: int, allow_capped=False):
+        _check(lib.hmrm_render_device_wait(self._h, ticket), allow=(HMRM_E_NOTERM,) if allow_capped else ())
 
     def take_capped(self, stream: int = 0, allow_capped=False) -> int:
         """Rays of the launches enqueued on `stream` that reached the step cap since the last call

@@ -3,8 +3,8 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 hm = importlib.import_module("heightmap-ray-marcher_amd")
 for name in sys.argv[1:] or ["C3", "C5"]:
-    wl = hm.synth.WORKLOADS[name]
-    rgb, cmap = hm.synth.synth_maps(wl.map_size)
+    wl = hm.synth.WORKLOADS[name] if "/" not in name else hm.synth.content_workload(*name.split("/"))  # e.g. C3/white
+    rgb, cmap = wl.maps()
     gw = float(os.environ.get("HMRM_DIAG_GW", "1"))  # the same scene scaled to another grid width
     params = wl.scene_params()
     cam = wl.camera()

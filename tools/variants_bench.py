@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 hmrm = importlib.import_module("heightmap-ray-marcher_amd")
 variants = os.environ.get("VARIANTS", "leap,group,simple").split(",")
 for name in sys.argv[1:] or ["C3"]:
-    wl = hmrm.synth.WORKLOADS[name]
-    rgb, cmap = hmrm.synth.synth_maps(wl.map_size)
+    wl = hmrm.synth.WORKLOADS[name] if "/" not in name else hmrm.synth.content_workload(*name.split("/"))  # e.g. C3/white
+    rgb, cmap = wl.maps()
     scene = hmrm.Scene(rgb, cmap, wl.scene_params())
     cam = wl.camera()
     os.environ["HMRM_KERNEL"] = "leap"
