@@ -36,7 +36,7 @@ N = 1: `value` / `ms_per_step` = K frames of the workload's static pose launched
                            of the HBM peak (the figure that formula is defined for);
          rough_terrain     the headline camera over maps built to defeat the traversal (white noise,
                            a 255-spike per 256^2 block, needles on a plateau, a canyon flown at low
-                           altitude): production kernel against the plain 4-step groups.
+                           altitude): the library as shipped against the plain 4-step groups.
 N > 1: one process per GPU over RCCL, maps replicated.  `value` = frames of BASELINE configs[4]'s
        64-frame orbit ("C5"; `--workload` overrides), frame k on GPU k mod N, K frames per GPU on one
        stream each, no data-path collective, scaling "weak".  The same line carries `rccl_ranks`
@@ -714,7 +714,8 @@ def main(argv=None):
                 sc = hmrm.Scene(*wr.maps(), wr.scene_params())
                 cr = wr.camera()
                 fbr, sr, _, _ = sc.render_stats(cr)
-                precondition(sc, cr)
+                precondition(sc, cr)  # (includes the scene's one-time kernel probe: leaps or plain groups, whichever measured faster)
+                chosen = ("leaps", "groups", "literal")[sc.kernel_choice()]
                 leap_ms = sc.bench_kernel_ms(cr, n_r)
 
                 def group():
@@ -723,13 +724,14 @@ def main(argv=None):
                 group_ms = with_kernel("group", group)
                 if not np.array_equal(sc.render(cr), fbr):
                     raise SystemExit(f"bench.py: rough_terrain/{kind}: hmrm_render and hmrm_render_stats disagree")
-                rough[kind] = {"workload": workload_text(wr), "kernel_ms": leap_ms, "group_kernel_ms": group_ms,
-                               "leap_over_group": leap_ms / group_ms, "ray_steps_per_frame": int(sr.steps),
+                rough[kind] = {"workload": workload_text(wr), "kernel_ms": leap_ms, "kernel_chosen_by_probe": chosen,
+                               "group_kernel_ms": group_ms, "over_group": leap_ms / group_ms, "ray_steps_per_frame": int(sr.steps),
                                "value": int(sr.steps) / (leap_ms * 1e-3), "mrays_per_s": int(sr.rays) / (leap_ms * 1e-3) / 1e6,
                                "executed_per_frame": executed(sr)}
                 sc.close()
-            rough["note"] = ("same camera as the headline (canyon: low and level, down the corridor); kernel_ms by HIP events, "
-                             f"{n_r} launches; group_kernel_ms = HMRM_KERNEL=group (speculative 4-step groups, no leaps)")
+            rough["note"] = ("same camera as the headline (canyon: low and level, down the corridor); kernel_ms = the library as shipped "
+                             f"(HIP events, {n_r} launches): the production kernel unless the scene's one-time probe measured the plain "
+                             "groups at least 3 % faster; group_kernel_ms = HMRM_KERNEL=group (speculative 4-step groups, no leaps)")
             secondary["rough_terrain"] = rough
 
         # ---- C4 on one GPU (8192^2 maps: the scene of the headline is released first)

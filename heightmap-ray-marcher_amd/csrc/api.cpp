@@ -61,10 +61,7 @@ struct Knobs {
 	int min_level = -1;                  // HMRM_MIN_LEVEL (tools)
 	int finest_pause = -1;               // HMRM_FINEST_PAUSE (tools)
 	bool order_verbose = false;          // HMRM_ORDER_VERBOSE=1 (tools): report every calibration on stderr
-	int persist = 0;                     // HMRM_PERSIST=1 (experiment): full frames through the persistent-tile kernel
-	int persist_chunk = 8;               // HMRM_PERSIST_CHUNK: wave tiles per dequeue on the rows behind the marching ones
-	int persist_waves = 0;               // HMRM_PERSIST_WAVES: waves to launch (0 = every slot of the device)
-	int persist_single = -1;             // HMRM_PERSIST_SINGLE: grid rows handed out one wave tile at a time (-1 = the marching rows)
+	bool try_group = true;               // HMRM_TRY_GROUP=0: the calibration does not time the plain-groups kernel against the leap kernel
 	int seg_n = 0;                       // HMRM_TILE_SEGMENTS=b0:c0,b1:c1,.. (tools): tile-row pieces to start first, in this order
 	int seg_b[3] = {0, 0, 0}, seg_c[3] = {0, 0, 0};
 };
@@ -85,10 +82,7 @@ Knobs read_knobs() {
 	}
 	if (const char *s = getenv("HMRM_DIAG_ITERS")) k.diag_mode = atoi(s);
 	if (const char *s = getenv("HMRM_ORDER_VERBOSE")) k.order_verbose = s[0] == '1';
-	if (const char *s = getenv("HMRM_PERSIST")) k.persist = atoi(s);
-	if (const char *s = getenv("HMRM_PERSIST_CHUNK")) k.persist_chunk = std::max(1, atoi(s));
-	if (const char *s = getenv("HMRM_PERSIST_WAVES")) k.persist_waves = std::max(0, atoi(s));
-	if (const char *s = getenv("HMRM_PERSIST_SINGLE")) k.persist_single = atoi(s);
+	if (const char *s = getenv("HMRM_TRY_GROUP")) k.try_group = s[0] != '0';
 	if (const char *s = getenv("HMRM_TILE_SEGMENTS")) {
 		int b = 0, c = 0, used = 0;
 		while (k.seg_n < 3 && sscanf(s, "%d:%d%n", &b, &c, &used) == 2 && b >= 0 && c > 0) {
@@ -132,12 +126,17 @@ struct FrameSlot {
 	// Launch order calibrated by measurement (plan_order_from_measurement below): a short list of trial orders, each
 	// timed by one measured full-frame launch -- [0] the rotation, then the model's plan and a generic head / tail /
 	// middle split of the measured hot range -- after which the one with the shortest measured makespan stays.
+	// The last candidate is not an order but the OTHER KERNEL: the plain speculative groups without leaps.  On content
+	// that admits no jumps (needles on a plateau, white noise seen from a perspective camera: profiles/r04_content.txt)
+	// the leap kernel's attempts are pure overhead, up to 15 %; a camera that is rendered repeatedly finds that out by
+	// measurement and stays with the faster kernel (which must win by 3 %).  Same pixels either way.
 	struct OrderTrial {
 		int n = 0, b[3] = {0, 0, 0}, c[3] = {0, 0, 0}; // pieces (n = 0: the plain rotation)
+		bool group = false;                            // the trial runs the plain 4-step groups (no leaps), rotation order
 		double makespan = 0.0;                         // measured, ticks (the shorter of kOrderSamples launches); 0 = not yet
 		int samples = 0;
 	};
-	OrderTrial trials[3];
+	OrderTrial trials[4];
 	int n_trials = 1;              // known so far (the candidates are made from the rotation's records)
 	int trial_in_flight = -1;      // the trial whose measured launch has not been read yet
 	int order_best = -1;           // settled: index into trials (-1: still calibrating, the rotation is used)
@@ -167,10 +166,6 @@ struct StreamCtx {
 	unsigned long long capped_seen = 0; // value of [2] the host has already reported
 	// recorded behind every launch: what a recycled context waits for (the caller's stream handle may be gone by then)
 	hipEvent_t last_launch = nullptr;
-	// persistent-tile kernel: kHeadSets sets of queue heads, used in turn by the stream's launches (launch n zeroes the
-	// set launch n + kHeadSets / 2 will use: stream order keeps the three apart)
-	unsigned *d_heads = nullptr;
-	uint32_t persist_launches = 0;
 };
 
 // One slot of the asynchronous read-back ring (hmrm_render_begin/_wait/_release): a device frame
@@ -248,7 +243,13 @@ struct hmrm_scene {
 		hmrm_scene_params params;
 		uint64_t thr_max_bits;
 		int n, b[3], c[3];
+		bool group;
 	};
+	// Which kernel suits the scene's content is probed ONCE per scene and height update, by the first camera that gets
+	// calibrated (two launches of the plain groups cost 3-6 ms on a 4K frame where leaps pay: too much to spend per
+	// camera); every other camera -- a moving one is never calibrated -- renders with the kernel that probe chose.
+	bool kernel_probed = false;
+	bool last_settled_group = false;
 	std::vector<SettledOrder> settled;
 };
 
@@ -274,7 +275,6 @@ void destroy_ctx(StreamCtx *c) {
 	if (c->d_arena) (void)hipFree(c->d_arena);
 	if (c->h_arena) (void)hipHostFree(c->h_arena);
 	if (c->d_counters) (void)hipFree(c->d_counters);
-	if (c->d_heads) (void)hipFree(c->d_heads);
 	if (c->last_launch) (void)hipEventDestroy(c->last_launch);
 	delete c;
 }
@@ -479,6 +479,7 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 			const hmrm_scene::SettledOrder &so = s->settled[k];
 			if (memcmp(&so.cam, cam, sizeof *cam) != 0 || memcmp(&so.params, &s->params, sizeof s->params) != 0 || so.thr_max_bits != thr_bits) continue;
 			slot->trials[1].n = so.n;
+			slot->trials[1].group = so.group;
 			for (int j = 0; j < 3; ++j) { slot->trials[1].b[j] = so.b[j]; slot->trials[1].c[j] = so.c[j]; }
 			slot->n_trials = 2;
 			slot->order_best = 1;
@@ -504,7 +505,8 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
                  uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats) {
 	hmrm::RowMap rows_in_order = rows;
 	bool measure_now = false;
-	int tiles_y = 0, trial_now = -1, rot_used = 0;
+	int tiles_y = 0, trial_now = -1;
+	bool use_group = false; // render with the plain groups (the calibration measured them faster on this content)
 	{
 		int tile_w = 1, tile_h = 1;
 		hmrm::render_tile_shape(&tile_w, &tile_h);
@@ -514,7 +516,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 		int nb = pieces ? s->knobs.seg_n : 0, b[3] = {s->knobs.seg_b[0], s->knobs.seg_b[1], s->knobs.seg_b[2]},
 		    c3[3] = {s->knobs.seg_c[0], s->knobs.seg_c[1], s->knobs.seg_c[2]};
 		// calibration (see plan_order_from_measurement): full frames of the production kernel only
-		const bool eligible = !pieces && !stats && s->knobs.tile_order && s->knobs.order_mode == 2 && s->knobs.kernel != 2 && !s->knobs.persist &&
+		const bool eligible = !pieces && !stats && s->knobs.tile_order && s->knobs.order_mode == 2 && s->knobs.kernel != 2 &&
 		                      rows.band_rows == 0 && rows.row_begin == 0 && rows.local_rows == f.screen_h && tiles_y >= 12 &&
 		                      tiles_y <= kMaxMeasRows && s->map_w < (1 << 24) && s->map_h < (1 << 24);
 		if (eligible) {
@@ -535,11 +537,18 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 					const bool same = split.n == plan.n && slot->n_trials > 1 && memcmp(split.b, plan.b, sizeof split.b) == 0 &&
 					                  memcmp(split.c, plan.c, sizeof split.c) == 0;
 					if (split.n > 0 && !same) ++slot->n_trials;
+					if (s->knobs.kernel == 0 && s->knobs.try_group && !s->kernel_probed) { // the other kernel, under the rotation
+						s->kernel_probed = true; // (this record's trials hold the probe: one camera per scene)
+						FrameSlot::OrderTrial &g = slot->trials[slot->n_trials];
+						g = FrameSlot::OrderTrial();
+						g.group = true;
+						++slot->n_trials;
+					}
 				}
 				if (s->knobs.order_verbose) {
 					fprintf(stderr, "hmrm order: trial %d of %d tile rows measured, makespan %.1f us:", slot->trial_in_flight, tiles_y, t.makespan / 100.0);
 					for (int k = 0; k < t.n; ++k) fprintf(stderr, " [%d,%d)", t.b[k], t.b[k] + t.c[k]);
-					fprintf(stderr, "%s\n", t.n ? "" : " rotation");
+					fprintf(stderr, "%s\n", t.group ? " plain groups, rotation" : (t.n ? "" : " rotation"));
 				}
 				slot->trial_in_flight = -1;
 				int next = -1;
@@ -548,14 +557,19 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 				if (next < 0) { // all timed: the shortest stays; another order must beat the rotation by 1 %
 					int best = 0;
 					for (int k = 1; k < slot->n_trials; ++k)
-						if (slot->trials[k].makespan < 0.99 * slot->trials[0].makespan && slot->trials[k].makespan < slot->trials[best].makespan) best = k;
+						if (!slot->trials[k].group && slot->trials[k].makespan < 0.99 * slot->trials[0].makespan && slot->trials[k].makespan < slot->trials[best].makespan) best = k;
+					for (int k = 1; k < slot->n_trials; ++k) // (the other kernel must beat the best order of this one by 3 %)
+						if (slot->trials[k].group && slot->trials[k].makespan < 0.97 * slot->trials[best].makespan) best = k;
 					slot->order_best = best;
+					for (int k = 1; k < slot->n_trials; ++k)
+						if (slot->trials[k].group) s->last_settled_group = slot->trials[best].group; // (the probing record decides)
 					if (s->knobs.order_verbose) fprintf(stderr, "hmrm order: settled on trial %d\n", best);
 					hmrm_scene::SettledOrder so{};
 					so.cam = slot->cam;
 					so.params = slot->params;
 					so.thr_max_bits = slot->thr_max_bits;
 					so.n = slot->trials[best].n;
+					so.group = slot->trials[best].group;
 					for (int k = 0; k < 3; ++k) { so.b[k] = slot->trials[best].b[k]; so.c[k] = slot->trials[best].c[k]; }
 					if (s->settled.size() >= 256) s->settled.erase(s->settled.begin());
 					s->settled.push_back(so);
@@ -572,9 +586,14 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 			}
 			nb = slot->trials[use].n;
 			for (int k = 0; k < nb; ++k) { b[k] = slot->trials[use].b[k]; c3[k] = slot->trials[use].c[k]; }
+			// the probing record times both kernels; everybody else renders with the one the scene's probe chose
+			bool probing = false;
+			for (int k = 1; k < slot->n_trials; ++k) probing = probing || slot->trials[k].group;
+			use_group = (probing && (slot->order_best >= 0 || measure_now)) ? slot->trials[use].group : s->last_settled_group;
+		} else if (!stats && s->knobs.kernel == 0 && s->knobs.try_group) {
+			use_group = s->last_settled_group; // strips, bands, small frames: the scene's last measured choice
 		}
 		hmrm::set_tile_order(&rows_in_order, tiles_y, rot, nb, b, c3);
-		rot_used = rot;
 	}
 	if (measure_now) {
 		if (!c->d_meas) {
@@ -597,30 +616,8 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 	if ((s->knobs.kernel == 2 || huge_side) && f.sampling == 0) { // (the literal loop only knows the reference's sampling)
 		HIP_TRY(hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters, d_steps,
 		                            d_entry, stats, c->stream));
-	} else if (s->knobs.persist && s->knobs.kernel == 0 && !stats && !measure_now && rows.band_rows == 0 && tiles_y >= 2) {
-		// experiment (HMRM_PERSIST=1): resident waves pull the wave tiles from a queue, in the rotation's order
-		constexpr int kHeadSets = 64;
-		constexpr size_t kSetWords = (size_t)hmrm::kPersistHeads * 32;
-		if (!c->d_heads) {
-			HIP_TRY(hipMalloc((void **)&c->d_heads, kHeadSets * kSetWords * sizeof(unsigned)));
-			HIP_TRY(hipMemsetAsync(c->d_heads, 0, kHeadSets * kSetWords * sizeof(unsigned), c->stream));
-		}
-		const uint32_t n = c->persist_launches++;
-		// the rotation starts at the first marching tile row and wraps: the tile rows in front of it come last
-		const int single = s->knobs.persist_single >= 0 ? s->knobs.persist_single : tiles_y - rot_used;
-		const hipError_t e = hmrm::launch_render_persist(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px, c->d_counters,
-		                                                 c->d_heads + (n % kHeadSets) * kSetWords,
-		                                                 c->d_heads + ((n + kHeadSets / 2) % kHeadSets) * kSetWords, single,
-		                                                 s->knobs.persist_chunk, s->knobs.persist_waves, c->stream);
-		if (e == hipErrorNotSupported) {
-			--c->persist_launches;
-			HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
-			                                 c->d_counters, d_steps, d_entry, stats, true, c->stream));
-		} else {
-			HIP_TRY(e);
-		}
 	} else {
-		const bool leap = s->knobs.kernel != 1;
+		const bool leap = s->knobs.kernel != 1 && !use_group;
 		HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
 		                                 c->d_counters, d_steps, d_entry, stats, leap, c->stream));
 	}
@@ -743,6 +740,8 @@ int run_update_heights(hmrm_scene *s) {
 	for (StreamCtx *c : s->ctxs)
 		for (FrameSlot &sl : c->slots) sl.valid = false;
 	s->settled.clear();
+	s->last_settled_group = false; // (new heights: new content)
+	s->kernel_probed = false;
 	unsigned long long key = 0;
 	HIP_TRY(hipMemcpyAsync(&key, s->d_maxkey, sizeof key, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -893,6 +892,13 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	delete s;
 }
 
+int hmrm_debug_kernel_choice(const hmrm_scene *s) {
+	if (!s) return fail(HMRM_E_ARG, "NULL argument");
+	std::lock_guard<std::mutex> lk(const_cast<hmrm_scene *>(s)->mu);
+	if (s->knobs.kernel != 0) return s->knobs.kernel; // forced by HMRM_KERNEL: 1 group, 2 simple
+	return s->last_settled_group ? 1 : 0;
+}
+
 int hmrm_debug_reload_env(hmrm_scene *s) {
 	if (!s) return fail(HMRM_E_ARG, "NULL argument");
 	HIP_TRY(hipSetDevice(s->device));
@@ -902,6 +908,8 @@ int hmrm_debug_reload_env(hmrm_scene *s) {
 	// changed must not be compared with ones measured after, and an order settled for the old kernel must not be
 	// adopted for the new one.  Every record goes back to "uncalibrated" (pixels never depended on any of this).
 	s->settled.clear();
+	s->last_settled_group = false;
+	s->kernel_probed = false;
 	for (StreamCtx *c : s->ctxs)
 		for (FrameSlot &sl : c->slots) {
 			if (sl.trial_in_flight >= 0 && sl.measured) HIP_TRY(hipEventSynchronize(sl.measured)); // (its read-back targets the slot's records)

@@ -30,17 +30,6 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
                               bool leap, hipStream_t stream);
-// Persistent-tile variant of the production kernel (render_fast.hip k_render_persist; full contiguous frames, not
-// instrumented): a grid of resident waves pulls 8 x 8-pixel wave tiles, in the launch order of `rows`, from kPersistHeads
-// queue heads (one 128-byte line each).  `heads` = this launch's heads, all zero; `heads_zero` = the set a later launch of
-// the stream will use (zeroed by this one).  The first `single_rows` grid rows are handed out one wave tile at a time
-// (marching rows), the rest `chunk` wave tiles per dequeue (rows that mostly miss).  `waves` = waves to launch
-// (0 = every slot of the device).  Returns hipErrorNotSupported when the frame is too large for the kernel's index arithmetic.
-constexpr int kPersistHeads = 32;
-hipError_t launch_render_persist(const DevFrame &f, const RowMap &rows, const double *d_thr, const float *d_thr32,
-                                 const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
-                                 unsigned long long *d_counters, unsigned *heads, unsigned *heads_zero, int single_rows,
-                                 int chunk, int waves, hipStream_t stream);
 // thr32[i] = (float)thr[i], round to nearest (the "float heights" mode).
 hipError_t launch_thr_to_float(const double *d_thr, float *d_thr32, int64_t n, hipStream_t stream);
 // 3x3 maximum filter of the thr table (bounds every bilinear interpolation, render_fast.hip).

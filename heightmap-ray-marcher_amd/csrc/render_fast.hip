@@ -86,27 +86,6 @@ constexpr bool kAdaptive = kAdaptAfter > 0;
 #endif
 constexpr bool kEarlyLoad = HMRM_EARLY_LOAD != 0;
 
-// HMRM_GIVEUP (default 4; 0 = off): back-off of a ray whose attempts keep being refused at the FINEST level because it is
-// below that window's maximum (white-noise heights, needles on a plateau: every 4-cell window holds a tall cell, so such
-// a ray cannot jump until it hits -- and each refused attempt costs about as much as the group of real steps it delays).
-// The j-th consecutive refusal is followed by finest_pause + 2^(j-1) - 1 groups (j capped at HMRM_GIVEUP: + 0, 1, 3, 7),
-// so a ray that can never jump again spends a vanishing share of its trips on attempts while one that is refused a
-// few times (skimming a ridge) tries again at most twice as late as it would have.  A successful jump resets the count.
-// Performance only (profiles/r04_content.txt: white noise 1.06 -> x of the plain groups).
-#ifndef HMRM_GIVEUP
-#define HMRM_GIVEUP 4
-#endif
-constexpr int kGiveUp = HMRM_GIVEUP;
-// HMRM_WAVE_GIVEUP (default 8; 0 = off): the same at the level of the wave, where the cost is -- a wave executes the attempt
-// block whenever ANY of its lanes attempts, so lanes backing off one by one save little.  After HMRM_WAVE_GIVEUP trips in a
-// row in which lanes attempted and none jumped, nobody in the wave attempts for 4, 8, .. 64 trips (doubling while that keeps
-// happening; one successful jump resets it): on content that admits no jumps the kernel then runs the plain groups at the
-// plain groups' speed.  Wave-uniform state (scalar registers).  Performance only.
-#ifndef HMRM_WAVE_GIVEUP
-#define HMRM_WAVE_GIVEUP 8
-#endif
-constexpr int kWaveGiveUp = HMRM_WAVE_GIVEUP;
-
 // ---- bilinear quality mode (HMRM_BILINEAR; a build-side addition, not in the reference) ----
 // Same definition, operation for operation, as oracle/hmrm_oracle.c "bilinear quality mode":
 // values sit at cell centres; u = q - 0.5, t = u - floor(u), neighbours clamp(floor(u)) and
@@ -175,8 +154,9 @@ __device__ TimelineRec *g_timeline = nullptr;
 // SAMP: 0 nearest cell (the reference), 1 bilinear quality mode, 2 nearest cell with float thresholds
 // (`thr` then points at the float copy of the table).
 // One wave's 8 x 8 pixels: wave `wave` of the workgroup-sized tile (tile_x, grid row gy).  Returns the tile row rendered
-// (-1: the grid row does not exist).  Inlined into k_render_fast (one tile per workgroup, the tile is blockIdx) and
-// into k_render_persist (waves pull tiles from a queue).
+// (-1: the grid row does not exist).  k_render_fast calls it with the tile = blockIdx (one tile per workgroup); round 4's
+// persistent-tile experiment (resident waves pulling tiles from queue heads) called it in a loop and was 1.4-1.9 x slower:
+// profiles/r04_experiments.txt section 1, code at commit 80527e9.
 template <int PROJ, bool STATS, int GWM, bool LEAP, int SAMP>
 __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap &rows, const double *__restrict__ thr,
                                                 const uint32_t *__restrict__ cmap, uint32_t *__restrict__ out,
@@ -237,7 +217,6 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 					lev = (l >= f.min_level && lateral <= (double)((win_strides(l) - 1) << mip_stride_shift(l))) ? l : lev;
 			}
 			int cooldown = 0, fails = 0;
-			int refused_fine = 0; // consecutive height refusals at the finest level (kGiveUp)
 			int jumps = 0; // successful jumps so far (kAdaptive)
 			Axis ax, ay, az;
 			ax.key = ay.key = az.key = 0xfffffffeu; // never matches: forces the first refresh
@@ -253,15 +232,13 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 			// branch any of its lanes takes, and exec-mask juggling per `if` costs as much as
 			// the arithmetic it guards.  Values are computed for all lanes and selected.
 			bool done = entry_nan;
-			int w_state = 0; // (kWaveGiveUp; wave-uniform, one scalar register: pause | streak << 8 | doublings << 12)
 			while (!done) {
 				bool skip_group = false;
 				diag.begin_trip();
 				// ---------------------------------------------------------- leap
 				if (LEAP) {
-					const bool attempt = kWaveGiveUp > 0 ? (cooldown == 0 && (w_state & 0xff) == 0) : cooldown == 0;
-					cooldown -= kWaveGiveUp > 0 ? (cooldown > 0 ? 1 : 0) : (attempt ? 0 : 1);
-					bool jumped = false;
+					const bool attempt = cooldown == 0;
+					cooldown -= attempt ? 0 : 1;
 					if (attempt) {
 						diag.on_attempt();
 						// Order of the block (HMRM_EARLY_LOAD): the window look-up depends on the position and the level only, so
@@ -280,10 +257,13 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						};
 						if (!kEarlyLoad) refresh_stale();
 						bool near0 = false;
-						double qx = cell_coord_fast<GWM>(x, f, near0), qy = cell_coord_fast<GWM>(-y, f, near0);
-						if (GWM == 2 && near0) { qx = x / f.grid_width; qy = -y / f.grid_width; }
+						const double qx = cell_coord_fast<GWM>(x, f, near0), qy = cell_coord_fast<GWM>(-y, f, near0);
+						// (general grid widths: a start or landing point within 2^-20 of a cell boundary -- one attempt in 2^18 --
+						// would need the true quotient to name its cell.  Such an attempt is simply not made / refused: the ray marches
+						// a group, whose samples do divide for real.  Four inlined divisions and their temporaries left this block:
+						// 76 -> 68 vector registers for the general instantiations.)
 						const int gx = cvt_i32_sat(qx), gy = GWM == 0 ? cvt_i32_sat_neg(y) : cvt_i32_sat(qy);
-						const bool inb0 = (unsigned)gx < wlim && (unsigned)gy < hlim;
+						const bool inb0 = (unsigned)gx < wlim && (unsigned)gy < hlim && !(GWM == 2 && near0);
 						const bool top = lev == kTopLevel;
 						// window (ix,iy) of level lev: S = 4 << lev cells wide, one every 1<<hs cells.  The whole map is
 						// the one window of the top plane: with hs = 28 every in-grid cell has ix = iy = 0 and the
@@ -366,13 +346,12 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 							const double xm = x + nn * ax.delta, ym = y + nn * ay.delta, zm = z + nn * az.delta;
 							const double xn = kCross ? xm + sx : xm, yn = kCross ? ym + sy : ym, zn = kCross ? zm + sz : zm;
 							bool nearn = false;
-							double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
-							if (GWM == 2 && nearn) { qxn = xn / f.grid_width; qyn = -yn / f.grid_width; }
+							const double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
 							const int gxn = cvt_i32_sat(qxn), gyn = GWM == 0 ? cvt_i32_sat_neg(yn) : cvt_i32_sat(qyn);
 							const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim; // (diagnostics only)
 							// (inside the window implies inside the grid: the spans were cut at the map's edge)
 							// (kStepsLeft: n <= left of every axis, so the landing point is inside the three binades by count)
-							ok = can && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
+							ok = can && !(GWM == 2 && nearn) && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
 							     (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
 							     (kStepsLeft || (axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn)));
 							diag.on_landing_refused(f, can && !ok, inbn,
@@ -425,29 +404,12 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						const int fails_before = fails;
 						lev = hl ? finer : (go_up ? coarser : lev);
 						fails = (crossed | (hl & ok)) ? 0 : fails + (other ? 1 : 0);
-						const bool refused_here = hl & !ok & at_finest;
-						int fine_pause = f.finest_pause;
-						if (kGiveUp > 0) {
-							fine_pause += (1 << refused_fine) - 1; // (the count before this refusal: 0, 1, 3, 7 extra groups)
-							refused_fine = ok ? 0 : (refused_here && refused_fine < kGiveUp - 1 ? refused_fine + 1 : refused_fine);
-						}
-						cooldown = refused_here ? fine_pause : (other ? (fails_before < 3 ? fails_before : 3) : 0);
+						cooldown = (hl & !ok & at_finest) ? f.finest_pause : (other ? (fails_before < 3 ? fails_before : 3) : 0);
 						// retry one level down without marching; after a jump look at the next window straight
 						// away -- unless the jump stopped at a binade boundary: only real steps cross it,
 						// another attempt here would just fail
 						// (kCross: the jump's last step has crossed it)
 						skip_group = (hl & !ok & !at_finest) | (ok & (kCross | !binade_bound));
-						jumped = ok;
-					}
-					if (kWaveGiveUp > 0) {
-						const bool any_attempt = __builtin_amdgcn_ballot_w64(attempt) != 0ull;
-						const bool any_jump = __builtin_amdgcn_ballot_w64(jumped) != 0ull;
-						w_state -= (w_state & 0xff) ? 1 : 0;
-						w_state = any_jump ? (w_state & 0xff) : w_state + (any_attempt ? 0x100 : 0);
-						if (((w_state >> 8) & 0xf) >= kWaveGiveUp) {
-							const int k = w_state >> 12;
-							w_state = ((k < 4 ? k + 1 : k) << 12) | (4 << k);
-						}
 					}
 				}
 				diag.on_trip(f, LEAP, skip_group);
@@ -465,29 +427,44 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 					Y[j] = Y[j - 1] + sy;
 					Z[j] = Z[j - 1] + sz;
 				}
-				double QX[kGroup], QY[kGroup];
+				// cells of the kGroup positions.  Only the integers are kept: the general-grid-width quotient q' is needed for
+				// nothing but its truncation (and the test whether it is too close to an integer to be trusted), and holding
+				// kGroup pairs of them cost the general instantiations 12 vector registers (76: 6 waves per SIMD).  The
+				// bilinear mode needs the exact quotients themselves (its weights) and keeps them.
+				double QX[BILINEAR ? kGroup : 1], QY[BILINEAR ? kGroup : 1];
 				bool near = false;
 #pragma unroll
 				for (int j = 0; j < kGroup; ++j) {
-					QX[j] = cell_coord_fast<GWM>(X[j], f, near);
-					QY[j] = cell_coord_fast<GWM>(-Y[j], f, near);
-				}
-				if (GWM == 2 && (near || BILINEAR)) { // on a cell boundary to within 2^-20 (or the exact q is needed): divide
-#pragma unroll
-					for (int j = 0; j < kGroup; ++j) {
-						QX[j] = X[j] / f.grid_width;
-						QY[j] = -Y[j] / f.grid_width;
+					int gx, gy;
+					if constexpr (BILINEAR && GWM != 0) { // (the exact q: true division unless the reciprocal is exact)
+						QX[j] = GWM == 2 ? X[j] / f.grid_width : X[j] * f.inv_grid_width;
+						QY[j] = GWM == 2 ? -Y[j] / f.grid_width : -Y[j] * f.inv_grid_width;
+						gx = cvt_i32_sat(QX[j]);
+						gy = cvt_i32_sat(QY[j]);
+					} else {
+						const double qx = cell_coord_fast<GWM>(X[j], f, near), qy = cell_coord_fast<GWM>(-Y[j], f, near);
+						if constexpr (BILINEAR) { QX[j] = qx; QY[j] = qy; }
+						gx = cvt_i32_sat(qx);                                       // hmap.cpp:1001-1004
+						gy = GWM == 0 ? cvt_i32_sat_neg(Y[j]) : cvt_i32_sat(qy);
 					}
-				}
-#pragma unroll
-				for (int j = 0; j < kGroup; ++j) {
-					const double qx = QX[j], qy = QY[j];
-					const int gx = cvt_i32_sat(qx), gy = GWM == 0 ? cvt_i32_sat_neg(Y[j]) : cvt_i32_sat(qy); // hmap.cpp:1001-1004
 					inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;      // hmap.cpp:1006-1011
 					cell[j] = inb[j] ? (unsigned)index_2d(gy, f.map_w, gx) : 0u;
 				}
+				if (GWM == 2 && !BILINEAR && near) { // some position is on a cell boundary to within 2^-20: divide for real
+#pragma unroll
+					for (int j = 0; j < kGroup; ++j) {
+						// (one division at a time: interleaved, their temporaries set the kernel's register count)
+						__builtin_amdgcn_sched_barrier(0);
+						const int gx = cvt_i32_sat(X[j] / f.grid_width);
+						__builtin_amdgcn_sched_barrier(0);
+						const int gy = cvt_i32_sat(-Y[j] / f.grid_width);
+						inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;
+						cell[j] = inb[j] ? (unsigned)index_2d(gy, f.map_w, gx) : 0u;
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				}
 				diag.load_begin(f, 18);
-				if (BILINEAR) {
+				if constexpr (BILINEAR) {
 #pragma unroll
 					for (int j = 0; j < kGroup; ++j) {
 						const Bil b = bil_setup(inb[j] ? QX[j] : 0.0, inb[j] ? QY[j] : 0.0, f.map_w, f.map_h);
@@ -520,7 +497,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 					budget -= taken;
 					done = first < kGroup;
 					if (hit) {
-						if (BILINEAR) {
+						if constexpr (BILINEAR) {
 							// (the weights are rebuilt for the one position that hit: cheaper than keeping
 							// kGroup sets of them alive)
 							double qxh = QX[0], qyh = QY[0];
@@ -622,88 +599,6 @@ __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR 
 		g_timeline[wave] = TimelineRec{tl_t0, (unsigned long long)__builtin_amdgcn_s_memrealtime(), xcc, 0u};
 	}
 #endif
-}
-
-// ------------------------------------------------------------ persistent tiles ----
-// The same wave tiles, pulled from a queue by a grid of resident waves instead of dispatched one workgroup per tile
-// (are the dispatch floor of the miss-only waves -- an all-miss 4K frame takes 0.031 ms of dispatch -- and
-// the 4.6-of-8 residency recoverable?).  Work list = the wave tiles (two per workgroup-sized tile) in the launch order of
-// `rows`.  Chunk c of the list belongs to head c mod kPersistHeads; a wave takes chunks from the head of its XCD slot until
-// that head runs out, then from the next head that has any left (one load of all the heads tells); it exits when that load
-// shows every head run out (heads only grow: every wave reaches that).  One returning atomic per dequeue, on 32 lines: a single word saturates at ~88 dequeues / us
-// (MI355X_MICROARCH.md), so marching rows (one wave tile per dequeue: a marching wave runs 20-60 us, handing several to one
-// wave would unbalance the launch) and rows that mostly miss (q.chunk per dequeue) are listed separately.
-struct PersistQueue {
-	unsigned *heads;      // kPersistHeads x 32 words, zero at launch
-	unsigned *heads_zero; // ... of a later launch of this stream: zeroed here
-	unsigned tiles_x;     // workgroup-sized tiles per grid row
-	unsigned magic;       // floor(2^32 / tiles_x) + 1: t / tiles_x == mulhi(t, magic) for t * tiles_x < 2^32
-	unsigned total;       // wave tiles of the launch
-	unsigned single;      // wave tiles handed out one per dequeue (the first rows of the launch order)
-	unsigned chunk;       // wave tiles per dequeue behind them
-	unsigned n_chunks;    // single + ceil((total - single) / chunk)
-};
-
-// (the tile loop keeps per-frame values in registers across tiles: 89 VGPRs = 5 waves per SIMD where the one-tile kernel
-// has 62 = 8; forcing 6 or 7 with HMRM_PERSIST_WAVES_PER_EU spills and was slower, profiles/r04_experiments.txt)
-#if defined(HMRM_PERSIST_WAVES_PER_EU) && HMRM_PERSIST_WAVES_PER_EU > 0
-#define HMRM_PERSIST_ATTR __attribute__((amdgpu_waves_per_eu(HMRM_PERSIST_WAVES_PER_EU, HMRM_PERSIST_WAVES_PER_EU)))
-#else
-#define HMRM_PERSIST_ATTR
-#endif
-static_assert(kPersistHeads == 32, "k_render_persist keeps the heads' state in a 32-bit lane mask");
-template <int PROJ, int GWM, int SAMP>
-__global__ __launch_bounds__(64) HMRM_PERSIST_ATTR void k_render_persist(const DevFrame f, const RowMap rows_arg, const double *__restrict__ thr,
-                                                       const uint32_t *__restrict__ cmap, uint32_t *__restrict__ out,
-                                                       int64_t out_stride_px, int tiles_y, StatsOut st, PersistQueue q) {
-	const int lane = (int)threadIdx.x;
-	RowMap rows = rows_arg;
-	rows.band_rows = 0; // (contiguous frames only, launch_render_persist: the band arithmetic folds away)
-	rows.measure = nullptr;
-	if (blockIdx.x == 0 && lane < kPersistHeads) q.heads_zero[lane * 32] = 0u;
-	unsigned xcc;
-	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-	// workgroups go round-robin to the XCDs: (blockIdx.x >> 3) tells the workgroups of one XCD apart
-	unsigned h = ((xcc & 7u) * (kPersistHeads / 8) + ((blockIdx.x >> 3) & (kPersistHeads / 8 - 1))) & (kPersistHeads - 1);
-	for (;;) {
-		unsigned k = 0;
-		if (lane == 0) k = __hip_atomic_fetch_add(&q.heads[h * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
-		const unsigned long long c64 = (unsigned long long)k * kPersistHeads + h;
-		if (c64 >= q.n_chunks) {
-			// This head has run out.  ONE load per lane reads all the heads (an atomic probe of each in turn costs a
-			// microsecond apiece under contention: 32 of them per wave at the end of a launch were most of its time);
-			// heads only grow, so "every head has run out" can be believed -- the wave is done -- and a head seen with
-			// work left is only a hint: its dequeue above decides.  Next: the first such head behind this one.
-			unsigned v = 0xffffffffu;
-			if (lane < kPersistHeads) v = __hip_atomic_load(&q.heads[lane * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const bool has = lane < kPersistHeads && (unsigned long long)v * kPersistHeads + (unsigned)lane < q.n_chunks;
-			const unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(has);
-			if (mask == 0u) break;
-			const unsigned rot = (mask >> h) | (h ? mask << (32u - h) : 0u); // bit j = head (h + j) mod 32
-			h = (h + (unsigned)__builtin_ctz(rot)) & (kPersistHeads - 1);
-			continue;
-		}
-		const unsigned c = (unsigned)c64;
-		unsigned w = c < q.single ? c : q.single + (c - q.single) * q.chunk;
-		unsigned cnt = c < q.single ? 1u : q.chunk;
-		cnt = cnt < q.total - w ? cnt : q.total - w;
-		unsigned t = w >> 1;
-		int wave = (int)(w & 1u);
-		unsigned gy = __umulhi(t, q.magic);
-		unsigned tx = t - gy * q.tiles_x;
-		for (unsigned j = 0; j < cnt; ++j) {
-			render_wave_tile<PROJ, false, GWM, true, SAMP>(f, rows, thr, cmap, out, out_stride_px, tiles_y, st, (int)tx, gy, wave, lane);
-			wave ^= 1;
-			if (wave == 0) {
-				++tx;
-				if (tx == q.tiles_x) {
-					tx = 0;
-					++gy;
-				}
-			}
-		}
-	}
 }
 
 // ---------------------------------------------------------------- pyramid ----
@@ -942,71 +837,6 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 	return hipGetLastError();
-}
-
-template <int PROJ, int GWM>
-static hipError_t launch_persist_samp(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
-                                      uint32_t *d_out, int64_t out_stride_px, int tiles_y, StatsOut st, const PersistQueue &q,
-                                      int waves, hipStream_t stream) {
-	auto go = [&](auto kernel) -> hipError_t {
-		static int slots = 0; // waves the device holds at once for this instantiation
-		if (slots == 0) {
-			int dev = 0, cus = 0, per_cu = 0;
-			hipError_t e = hipGetDevice(&dev);
-			if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-			if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0);
-			if (e != hipSuccess) return e;
-			slots = cus * per_cu;
-		}
-		int n = waves > 0 ? waves : slots;
-		if ((unsigned)n > q.n_chunks) n = (int)q.n_chunks;
-		hipLaunchKernelGGL(kernel, dim3((unsigned)(n < 1 ? 1 : n)), dim3(64), 0, stream, f, rows, d_thr, d_cmap, d_out, out_stride_px,
-		                   tiles_y, st, q);
-		return hipGetLastError();
-	};
-	if (f.sampling == 1) return go(k_render_persist<PROJ, GWM, 1>);
-	if (f.sampling == 2) return go(k_render_persist<PROJ, GWM, 2>);
-	return go(k_render_persist<PROJ, GWM, 0>);
-}
-
-template <int PROJ>
-static hipError_t launch_persist_gwm(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
-                                     uint32_t *d_out, int64_t out_stride_px, int tiles_y, StatsOut st, const PersistQueue &q,
-                                     int waves, hipStream_t stream) {
-	switch (f.grid_mode) {
-	case 0: return launch_persist_samp<PROJ, 0>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
-	case 1: return launch_persist_samp<PROJ, 1>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
-	default: return launch_persist_samp<PROJ, 2>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
-	}
-}
-
-hipError_t launch_render_persist(const DevFrame &f, const RowMap &rows, const double *d_thr_f64, const float *d_thr32,
-                                 const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
-                                 unsigned long long *d_counters, unsigned *heads, unsigned *heads_zero, int single_rows,
-                                 int chunk, int waves, hipStream_t stream) {
-	static_assert(kWavesX == 1 && kWavesY == 2, "k_render_persist decodes wave tiles of 1 x 2-wave workgroup tiles");
-	const double *d_thr = f.sampling == 2 ? reinterpret_cast<const double *>(d_thr32) : d_thr_f64;
-	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
-	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
-	if (tiles_x <= 0 || tiles_y <= 0) return hipSuccess;
-	// mulhi(t, magic) == t / tiles_x needs t * tiles_x < 2^32 for every tile index t
-	if ((uint64_t)tiles_x * tiles_x * tiles_y >= ((uint64_t)1 << 32) || chunk < 1 || rows.band_rows > 0) return hipErrorNotSupported;
-	PersistQueue q;
-	q.heads = heads;
-	q.heads_zero = heads_zero;
-	q.tiles_x = (unsigned)tiles_x;
-	q.magic = (unsigned)((((uint64_t)1 << 32) / (uint64_t)tiles_x) + 1);
-	q.total = 2u * (unsigned)tiles_x * (unsigned)tiles_y;
-	const int sr = single_rows < 0 ? 0 : (single_rows > tiles_y ? tiles_y : single_rows);
-	q.single = 2u * (unsigned)tiles_x * (unsigned)sr;
-	q.chunk = (unsigned)chunk;
-	q.n_chunks = q.single + (q.total - q.single + q.chunk - 1) / q.chunk;
-	StatsOut st{d_counters, nullptr, nullptr};
-	switch (f.projection) {
-	case 1: return launch_persist_gwm<1>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
-	case 2: return launch_persist_gwm<2>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
-	default: return launch_persist_gwm<3>(f, rows, d_thr, d_cmap, d_out, out_stride_px, tiles_y, st, q, waves, stream);
-	}
 }
 
 void render_tile_shape(int *tile_w, int *tile_h) {

@@ -105,6 +105,7 @@ def _load():
         "hmrm_render_rows_device": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, i32, i32, i32, i32, i32, vp]),
         "hmrm_scene_take_capped": (C.c_int, [vp, vp, C.POINTER(C.c_uint64)]),
         "hmrm_debug_reload_env": (C.c_int, [vp]),
+        "hmrm_debug_kernel_choice": (C.c_int, [vp]),
         "hmrm_debug_mip_layout": (C.c_int, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "hmrm_band_local_rows": (i32, [i32, i32, i32, i32]),
         "hmrm_render_stats": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(Stats), vp, vp]),
@@ -205,8 +206,7 @@ def set_device(i: int):
 
 # The library reads its environment knobs once per scene.  Tests and tools flip them
 # on live scenes, so the Python wrappers re-read them when one changed since the scene last looked.
-_ENV_KNOBS = ("HMRM_KERNEL", "HMRM_STEP_CAP", "HMRM_TILE_ORDER", "HMRM_DIAG_ITERS", "HMRM_MIN_LEVEL", "HMRM_FINEST_PAUSE", "HMRM_TILE_SEGMENTS", "HMRM_ORDER_VERBOSE",
-              "HMRM_PERSIST", "HMRM_PERSIST_CHUNK", "HMRM_PERSIST_WAVES", "HMRM_PERSIST_SINGLE")
+_ENV_KNOBS = ("HMRM_KERNEL", "HMRM_STEP_CAP", "HMRM_TILE_ORDER", "HMRM_DIAG_ITERS", "HMRM_MIN_LEVEL", "HMRM_FINEST_PAUSE", "HMRM_TILE_SEGMENTS", "HMRM_ORDER_VERBOSE", "HMRM_TRY_GROUP")
 
 
 def _env_snapshot():
@@ -336,6 +336,10 @@ class Scene:
         pos, dirv, d = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
         _check(lib.hmrm_debug_ray(self._h, C.byref(cam), px, py, pos, dirv, C.byref(d)))
         return np.array(pos[:]), np.array(dirv[:]), d.value
+
+    def kernel_choice(self) -> int:
+        """0 production kernel (leaps), 1 plain groups (forced, or chosen by the scene's probe), 2 literal loop."""
+        return int(lib.hmrm_debug_kernel_choice(self._h))
 
     def bench_kernel_ms(self, cam: Camera, iters: int) -> float:
         self._sync_env()

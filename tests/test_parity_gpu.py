@@ -189,10 +189,12 @@ def test_baseline_config_full_frame_vs_oracle(gpu, oracle, wl_name):
     scene.close()
 
 
-@pytest.mark.parametrize("wl_name", ["C3", "C3h", "C5"])
+@pytest.mark.parametrize("wl_name", ["C3", "C3h", "C5", "REFDEF"])
 def test_baseline_config_full_size_subsampled_and_properties(gpu, oracle, wl_name):
     """Full BASELINE size (3840x2160 over 4096^2): every 24th row against the oracle, plus
-    size-independent properties: determinism, instrumented == plain kernel, counters add up."""
+    size-independent properties: determinism, instrumented == plain kernel, counters add up.
+    REFDEF = the reference's own operating point (sample_config.txt:5-7: grid_width 0.01, step_dist 0.05 = 5 cells per
+    step) on the C5 frame: a general grid width with multi-cell steps, where leaps barely apply."""
     wl = gpu.synth.WORKLOADS[wl_name]
     rgb, cmap = gpu.synth.synth_maps(wl.map_size)
     params, cam = wl.scene_params(), wl.camera()
@@ -578,6 +580,82 @@ def test_async_ring_frames_in_flight(gpu, oracle):
             scene.render_release(tickets[k])
     with pytest.raises(gpu.HmrmError):
         scene.render_wait(tickets[0], (90, 160))                       # released: no such frame in flight
+    scene.close()
+
+
+def test_device_tickets_and_launch_lanes(gpu, oracle):
+    """hmrm_render_device_begin / _wait: frames into the caller's device memory through the scene's three launch lanes.
+    Several cameras in flight at once (each lane has its own tables and counters), every frame equal to the oracle's;
+    a capped ray is reported by the wait of its lane; and -- the point of the lanes, VERDICT r03 #8 -- a sequence of
+    small frames (BASELINE C2: 1080p over 1024^2) with three tickets in flight takes less GPU time per frame than the
+    same frames back to back on one stream, without the caller managing a stream (profiles/r04_lanes.txt)."""
+    import time
+    import torch
+    rgb, cmap = scenes.small_maps(96, 96, 41)
+    params = gpu.SceneParams.make(0.0, 10.0, grid_width=1.0)
+    heights = oracle.update_heightmap(rgb, params)
+    scene = gpu.Scene(rgb, cmap, params)
+    cams = [gpu.Camera.make(width=150 + 7 * k, height=90 + 3 * k, projection=1 + k % 3, hfov=gpu.degrees_to_rads(140 if k % 3 == 1 else 80),
+                            hang=gpu.degrees_to_rads(-45 + 5 * k), vang=gpu.degrees_to_rads(112), pos=(-30.0, 30.0, 40.0),
+                            ortho_width=0.8, step_dist=0.25, bg=(k, 2, 3)) for k in range(7)]
+    bufs = [torch.zeros((c.height, c.width + 5, 4), dtype=torch.uint8, device="cuda") for c in cams]  # (padded rows: a stride)
+    tickets = [scene.render_device_begin(c, b.data_ptr(), (c.width + 5) * 4) for c, b in zip(cams, bufs)]
+    assert len(set(tickets)) == len(tickets)
+    for t in reversed(tickets):
+        scene.render_device_wait(t)
+    for c, b in zip(cams, bufs):
+        ofb, *_ = oracle.render(oracle.make_cfg(c, params, 96, 96), heights, cmap)
+        got = b.cpu().numpy()
+        assert np.array_equal(got[:, :c.width], ofb), c.projection
+        assert (got[:, c.width:] == 0).all()
+    with pytest.raises(gpu.HmrmError):
+        scene.render_device_wait(tickets[0])  # (already waited for)
+    with env(HMRM_STEP_CAP=40):
+        slow = gpu.Camera.make(width=64, height=40, projection=1, hang=gpu.degrees_to_rads(-45), vang=gpu.degrees_to_rads(112),
+                               pos=(-30.0, 30.0, 40.0), step_dist=0.05)
+        out = torch.zeros((40, 64, 4), dtype=torch.uint8, device="cuda")
+        t = scene.render_device_begin(slow, out.data_ptr(), 64 * 4)
+        with pytest.raises(gpu.HmrmError) as e:
+            scene.render_device_wait(t)
+        assert e.value.code == gpu.HMRM_E_NOTERM
+    scene.close()
+    # the rate on C2
+    wl = gpu.synth.WORKLOADS["C2"]
+    scene = gpu.Scene(*wl.maps(), wl.scene_params())
+    cam = wl.camera()
+    W, H = cam.width, cam.height
+    fb = scene.render(cam)
+    out = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    for _ in range(12):
+        scene.bench_kernel_ms(cam, 1)
+
+    def one_stream(n):
+        s0 = torch.cuda.current_stream().cuda_stream
+        for _ in range(n):
+            scene.render_rows_device(cam, out[0].data_ptr(), W * 4, 0, H, stream=s0)
+
+    def lanes(n):
+        inflight = []
+        for i in range(n):
+            if len(inflight) == 3:
+                scene.render_device_wait(inflight.pop(0))
+            inflight.append(scene.render_device_begin(cam, out[i % 3].data_ptr(), W * 4))
+        for t in inflight:
+            scene.render_device_wait(t)
+
+    def ms(fn, n=300):
+        fn(30)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(n)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / n
+    a = min(ms(one_stream) for _ in range(3))
+    b = min(ms(lanes) for _ in range(3))
+    for o in out:
+        assert np.array_equal(o.cpu().numpy(), fb)
+    print(f"C2: one stream {a:.4f} ms per frame, three tickets in flight {b:.4f} ({b / a:.3f} x)")
+    assert b < 0.92 * a, (a, b)
     scene.close()
 
 
