@@ -258,12 +258,22 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						if (!kEarlyLoad) refresh_stale();
 						bool near0 = false;
 						const double qx = cell_coord_fast<GWM>(x, f, near0), qy = cell_coord_fast<GWM>(-y, f, near0);
-						// (general grid widths: a start or landing point within 2^-20 of a cell boundary -- one attempt in 2^18 --
-						// would need the true quotient to name its cell.  Such an attempt is simply not made / refused: the ray marches
-						// a group, whose samples do divide for real.  Four inlined divisions and their temporaries left this block:
-						// 76 -> 68 vector registers for the general instantiations.)
-						const int gx = cvt_i32_sat(qx), gy = GWM == 0 ? cvt_i32_sat_neg(y) : cvt_i32_sat(qy);
-						const bool inb0 = (unsigned)gx < wlim && (unsigned)gy < hlim && !(GWM == 2 && near0);
+						// General grid widths: a start or landing point within 2^-20 of a cell boundary would need the true quotient
+						// to name its cell.  The START divides for real then (a rare, wave-uniform branch: a coordinate that never
+						// moves -- orthographic rays along an axis -- can sit that close to a boundary for a whole ray).  The LANDING
+						// point does not: its cell is gxn or gxn - 1 (below), and the jump is accepted when BOTH lie inside the window
+						// -- two inlined divisions and their temporaries less at the block's point of highest register pressure.
+						// (Refusing such landings outright is wrong for speed: with 1 / grid_width an integer -- 0.05, 0.01 -- every
+						// power of two is a cell boundary, the landing point of a binade-limited jump is the first position behind
+						// one, always the same whatever the start, and a ray whose crossing step ends within 2^-20 of it was
+						// refused again and again until it had MARCHED there: 175 groups instead of one, the launch's last wave.)
+						double qx2 = qx, qy2 = qy;
+						if (GWM == 2 && __builtin_amdgcn_ballot_w64(near0) != 0ull) {
+							qx2 = near0 ? x / f.grid_width : qx;
+							qy2 = near0 ? -y / f.grid_width : qy;
+						}
+						const int gx = cvt_i32_sat(qx2), gy = GWM == 0 ? cvt_i32_sat_neg(y) : cvt_i32_sat(qy2);
+						const bool inb0 = (unsigned)gx < wlim && (unsigned)gy < hlim;
 						const bool top = lev == kTopLevel;
 						// window (ix,iy) of level lev: S = 4 << lev cells wide, one every 1<<hs cells.  The whole map is
 						// the one window of the top plane: with hs = 28 every in-grid cell has ix = iy = 0 and the
@@ -351,8 +361,11 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 							const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim; // (diagnostics only)
 							// (inside the window implies inside the grid: the spans were cut at the map's edge)
 							// (kStepsLeft: n <= left of every axis, so the landing point is inside the three binades by count)
-							ok = can && !(GWM == 2 && nearn) && (unsigned)(gxn - wx0) < (unsigned)wspan_x &&
-							     (unsigned)(gyn - wy0) < (unsigned)wspan_y && zn >= m &&
+							// (general grid widths, nearn: q' + 2^-20 lies in [k, k + 2^-19), so the landing cell is k = gxn or k - 1;
+							// both are asked to be inside the window, on both axes -- one flag serves the two)
+							const unsigned nm = (GWM == 2 && nearn) ? 1u : 0u;
+							ok = can && (unsigned)(gxn - wx0) - nm < (unsigned)wspan_x - nm &&
+							     (unsigned)(gyn - wy0) - nm < (unsigned)wspan_y - nm && zn >= m &&
 							     (kStepsLeft || (axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn)));
 							diag.on_landing_refused(f, can && !ok, inbn,
 							                        (unsigned)(gxn - wx0) < (unsigned)wspan_x && (unsigned)(gyn - wy0) < (unsigned)wspan_y, zn >= m);

@@ -469,6 +469,51 @@ def test_general_grid_width_full_frame(gpu, oracle, gw, sd):
     scene.close()
 
 
+def test_grid_width_with_integer_reciprocal_at_binade_boundaries(gpu, oracle):
+    """grid_width 0.05 (the reference's default, hmap.cpp:65) and 0.01 (its sample config): fl(1 / gw) is the integer 20 /
+    100, so every power of two of the world coordinates is also a CELL boundary, and the step of a jump that carries a
+    coordinate into its next binade lands right behind one.  Rays whose crossing step ends within 2^-20 cells of it (a
+    handful per 4K frame; round 4 found pixels (1758, 737) and (2263, 819) of the C3 camera at gw 0.05 that way) have a
+    landing cell the reciprocal cannot name: the kernel accepts such a jump only if both candidate cells lie inside the
+    window, and must still produce the reference's pixels and step counts.  Rows holding those rays, the orthographic
+    camera looking along an axis (coordinates that never move), and the time such a frame takes against the same
+    cells at grid_width 0.07 (the refusals marched 175 groups where one jump does: 1.35 x the frame time)."""
+    rgb, cmap = gpu.synth.synth_maps(4096)
+    times = {}
+    for gw in (0.05, 0.01, 0.07):
+        wl = gpu.synth.grid_workload("C3", gw)
+        params, cam = wl.scene_params(), wl.camera()
+        scene = gpu.Scene(rgb, cmap, params)
+        fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
+        assert np.array_equal(scene.render(cam), fb)
+        heights = oracle.update_heightmap(rgb, params)
+        cfg = oracle.make_cfg(cam, params, 4096, 4096)
+        for r in (737, 819, 880, 881, 964, 1090, 1216, 1500):
+            ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True, rows=(r, r + 1))
+            assert capped == 0 and np.array_equal(fb[r], ofb[r]), (gw, r)
+            assert np.array_equal(steps[r].astype(np.int64), osteps[r]) and np.array_equal(_bits(entry[r]), _bits(oentry[r])), (gw, r)
+        for _ in range(12):
+            scene.bench_kernel_ms(cam, 1)
+        times[gw] = min(scene.bench_kernel_ms(cam, 10) for _ in range(3))
+        scene.close()
+    print("kernel ms by grid width:", {k: round(v, 4) for k, v in times.items()})
+    assert times[0.05] < 1.15 * times[0.07] and times[0.01] < 1.15 * times[0.07], times
+    # coordinates that never move: orthographic rays along -y / +x over a 0.05 grid, columns a quarter cell apart from a
+    # corner that is a multiple of the cell: every 4th column of rays runs ALONG a cell boundary (to the last bits)
+    rgb2, cmap2 = scenes.small_maps(96, 96, 53)
+    params = gpu.SceneParams.make(0.0, 0.8, grid_width=0.05)
+    heights = oracle.update_heightmap(rgb2, params)
+    scene = gpu.Scene(rgb2, cmap2, params)
+    for hang_deg in (-90.0, 0.0):
+        cam = gpu.Camera.make(width=193, height=97, projection=3, hang=gpu.degrees_to_rads(hang_deg), vang=gpu.degrees_to_rads(120),
+                              pos=(2.4 if hang_deg else -1.0, 1.0 if hang_deg else -2.4, 2.0), ortho_width=0.0125 * 192 / 193, step_dist=0.0125, bg=(3, 4, 5))
+        ofb, total, capped, osteps, _ = oracle.render(oracle.make_cfg(cam, params, 96, 96), heights, cmap2, per_pixel=True)
+        fb, st, steps, _ = scene.render_stats(cam, per_pixel=True)
+        assert capped == 0 and np.array_equal(fb, ofb) and np.array_equal(steps.astype(np.int64), osteps), hang_deg
+        assert np.array_equal(scene.render(cam), ofb)
+    scene.close()
+
+
 def test_degenerate_parameters_agree_with_oracle(gpu, oracle):
     """Negative / huge step_dist, camera below the map, inverted height range: nothing special-cased
     in the reference, so whatever its loop does the kernels must do too (within the step cap)."""

@@ -76,6 +76,16 @@ for f in newest_per_dir(os.path.join(root, "trace", "**", "*_kernel_trace.csv"))
         if product_kernel(r["Kernel_Name"]):
             durations[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
+# One kernel renders a frame.  Others of the product's instantiations may appear a couple of times in a run -- the scene's
+# one-time kernel probe launches the plain-groups instantiation twice during the calibration -- and are left out: the
+# frame's kernel is the one with the most launches.
+if durations:
+    main = max(durations, key=lambda k: len(durations[k]))
+    durations = {main: durations[main]}
+if per_kernel:
+    main_pk = max(per_kernel, key=lambda k: max(len(v) for v in per_kernel[k].values()))
+    per_kernel = {main_pk: per_kernel[main_pk]}
+
 lines, frame = [], collections.defaultdict(float)
 for k in sorted(per_kernel):
     lines.append(f"== {k}")
@@ -140,6 +150,16 @@ if "SQ_INSTS_VALU" in frame:
 if "SQ_THREAD_CYCLES_VALU" in frame and "SQ_ACTIVE_INST_VALU" in frame:
     entry["lane_util"] = frame["SQ_THREAD_CYCLES_VALU"] / (64.0 * frame["SQ_ACTIVE_INST_VALU"])
     lines.append(f"lane utilisation (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU): {entry['lane_util']:.3f}")
+if "SQ_WAVE_CYCLES" in frame and frame["SQ_WAVE_CYCLES"] > 0:
+    # where a resident wave's time goes (SQ_WAVE_CYCLES counts quad-cycles of residency over all waves)
+    wc = frame["SQ_WAVE_CYCLES"]
+    wt = {"issuing": frame.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, "waiting_on_memory_or_dependency": frame.get("SQ_WAIT_INST_ANY", 0.0) / wc}
+    if "TCC_HIT_sum" in frame and "TCC_MISS_sum" in frame and frame["TCC_HIT_sum"] + frame["TCC_MISS_sum"] > 0:
+        wt["tcc_hit_rate"] = frame["TCC_HIT_sum"] / (frame["TCC_HIT_sum"] + frame["TCC_MISS_sum"])
+    if frame_ns:
+        wt["resident_waves_mean"] = wc * 4.0 / (frame_ns * 1e-9 * PEAK_CLOCK_HZ)
+    entry["wave_time"] = wt
+    lines.append("wave time: " + ", ".join(f"{k} {v:.3f}" for k, v in wt.items()))
 if frame_ns and "valu" in entry:
     simd_cycles = SIMDS * frame_ns * 1e-9 * PEAK_CLOCK_HZ
     lines.append(f"SIMD-cycles available per frame at 2.4 GHz over {frame_ns / 1e3:.1f} us: {simd_cycles:.3e}; "
