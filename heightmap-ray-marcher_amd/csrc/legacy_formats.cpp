@@ -516,12 +516,13 @@ bool hdr_picture(Stream &in, int req_comp, Image *out, std::string *err) {
 	const std::string dims = hdr_line(in);
 	if (dims.compare(0, 3, "-Y ") != 0) return refuse(err, "unsupported data layout");
 	char *rest = nullptr;
-	const long hh = std::strtol(dims.c_str() + 3, &rest, 10);
+	// (pixel contract: the loader this replaces narrows strtol's long to int BEFORE its range check, so a size of 2^32 + 5
+	// reads as 5 there; the same here -- the unsigned detour keeps the narrowing defined)
+	const int H = (int)(unsigned int)(unsigned long)std::strtol(dims.c_str() + 3, &rest, 10);
 	while (*rest == ' ') ++rest;
 	if (std::strncmp(rest, "+X ", 3) != 0) return refuse(err, "unsupported data layout");
-	const long ww = std::strtol(rest + 3, nullptr, 10);
-	if (hh > kMaxSide || ww > kMaxSide) return refuse(err, "too large");
-	const int W = (int)ww, H = (int)hh;
+	const int W = (int)(unsigned int)(unsigned long)std::strtol(rest + 3, nullptr, 10);
+	if (H > kMaxSide || W > kMaxSide) return refuse(err, "too large");
 	const int want = req_comp ? req_comp : 3;
 	if (W <= 0 || H <= 0) return refuse(err, "bad HDR size");
 	if ((uint64_t)W * (uint64_t)H * (uint64_t)want * sizeof(float) >= ((uint64_t)1 << 31)) return refuse(err, "too large");

@@ -216,6 +216,31 @@ def test_jpeg_heightmap_through_config(hmrm, tmp_path):
     assert np.array_equal(cfg.color_rgba(), data["rgb_420_q50/req4"])
 
 
+def test_hdr_dimensions_narrow_like_the_reference_loader(hmrm, stb_ref):
+    """stb narrows strtol's result to int BEFORE its size check (stb_image.h:7113-7120), so a Radiance
+    header that says 2^32 + 5 columns is a 5-column picture there; and 2^31 + 5 is negative: refused.  Same here, live
+    against the reference's own stb build where that exists."""
+    def hdr(h_txt, w_txt, pixels):
+        return (b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y " + h_txt + b" +X " + w_txt + b"\n" + bytes(pixels))
+    px = [128 + (7 * i) % 100 for i in range(4 * 5 * 2)]
+    for h_txt, w_txt, ok in ((b"2", b"5", True), (b"2", str(2 ** 32 + 5).encode(), True), (str(2 ** 32 + 2).encode(), b"5", True),
+                             (b"2", str(2 ** 31 + 5).encode(), False), (b"2", b"-5", False)):
+        blob = hdr(h_txt, w_txt, px)
+        for req in (0, 3, 4):
+            try:
+                got, n = hmrm.image_load_memory(blob, req)
+            except hmrm.HmrmError:
+                got = None
+            assert (got is not None) == ok, (h_txt, w_txt, req)
+            if ok:
+                assert got.shape[:2] == (2, 5)
+            if stb_ref is not None:
+                exp, _ = stb_ref.load(blob, req)
+                assert (exp is None) == (got is None), (h_txt, w_txt, req)
+                if exp is not None:
+                    assert np.array_equal(exp, got)
+
+
 def test_decode_large_random_png_roundtrip(hmrm, stb_ref):
     """A 300x200 map-like image through zlib level 9 (dynamic Huffman, long matches)."""
     import struct
