@@ -90,6 +90,19 @@ struct LoopDiag<true> {
 		if (f.diag_mode == 5) by_level(lev <= 3, 1u);
 		if (f.diag_mode == 6) by_level(ok && lev <= 3, 1u);
 		if (f.diag_mode == 7) by_level(ok && lev <= 3, (unsigned)n);
+		if (f.diag_mode == 21) { // what limited a successful jump: the window's maximum (z room) or something else; and their steps
+			x0 += (ok && z_bound) ? 1u : 0u;
+			x1 += (ok && !z_bound) ? 1u : 0u;
+			x2 += (ok && z_bound) ? (unsigned)n : 0u;
+			x3 += (ok && !z_bound) ? (unsigned)n : 0u;
+		}
+		if (f.diag_mode == 22) by_level(ok && z_bound, 1u); // z-limited jumps by level
+		if (f.diag_mode == 23) { // attempts and jumps of the levels above 3
+			x0 += (lev >= 3 && lev <= 4) ? 1u : 0u;
+			x1 += (lev >= 5 && lev <= 6) ? 1u : 0u;
+			x2 += (lev >= 7) ? 1u : 0u;
+			x3 += (ok && lev >= 7) ? (unsigned)n : 0u;
+		}
 		leaped += ok ? (unsigned)n : 0u;
 		leaps += ok ? 1u : 0u;
 	}

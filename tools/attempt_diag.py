@@ -28,6 +28,9 @@ for name in sys.argv[1:] or ["C3", "C5"]:
                          (13, ("attempt lane slots", "attempt useful", "group lane slots", "group useful")),
                          (14, ("attempt iters share<1/8", "1/8..1/4", "1/4..1/2", ">=1/2")),
                          (15, ("group iters share<1/8", "1/8..1/4", "1/4..1/2", ">=1/2")),
+                         (21, ("jumps limited by the window maximum", "jumps limited otherwise", "steps of the former", "steps of the latter")),
+                         (22, ("z-limited jumps L0", "L1", "L2", "L3+")),
+                         (23, ("attempts L3-4", "L5-6", "whole map", "steps jumped at whole-map level")),
                          (20, ("groups after a jump to a binade's end", "after an attempt without binade room", "without an attempt", "after other attempts"))):
         os.environ["HMRM_DIAG_ITERS"] = str(mode)
         cam.bg_r = mode  # defeat the frame cache
