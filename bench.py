@@ -636,13 +636,24 @@ def main(argv=None):
     check_headline()
 
     secondary = {}
+
+    def guarded(name, fn):
+        """A secondary block must not void the headline: an error of the runtime (out of memory, a refused call) is recorded
+        in the line under `secondary_errors`; a WRONG PIXEL is a SystemExit and still ends the run."""
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001  (SystemExit is not an Exception)
+            secondary.setdefault("secondary_errors", {})[name] = f"{type(e).__name__}: {e}"
+
     if not args.no_secondary and not multi:
         # ---- three frames in flight (a throughput mode for sequences of independent frames, hmap.cpp:1131-1144)
-        dt3, check3 = static_leg(scene, cam, args.steps, 50 + args.warmup, 3, fb_ref)
-        check3()
-        secondary["frames_in_flight"] = {"streams": 3, "ms_per_step": dt3 * 1e3 / args.steps,
-                                         "value": frame_steps * args.steps / dt3,
-                                         "note": "same K frames round-robin over 3 HIP streams; not the operating point of `roofline`"}
+        def blk_in_flight():
+            dt3, check3 = static_leg(scene, cam, args.steps, 50 + args.warmup, 3, fb_ref)
+            check3()
+            secondary["frames_in_flight"] = {"streams": 3, "ms_per_step": dt3 * 1e3 / args.steps,
+                                             "value": frame_steps * args.steps / dt3,
+                                             "note": "same K frames round-robin over 3 HIP streams; not the operating point of `roofline`"}
+        guarded("frames_in_flight", blk_in_flight)
 
         # ---- a moving camera: every timed frame's camera is new to the library (no pre-render), then the same
         # cameras again (per-stream cache of 64 records).  One stream, back to back, like the headline.
@@ -668,45 +679,52 @@ def main(argv=None):
             return {"frames": n, "ms_per_step": fresh * 1e3 / n, "cached_ms_per_step": cached * 1e3 / n,
                     "fresh_over_cached": fresh / cached, "value": steps_all / fresh, "unit": "ray-steps/s",
                     "mrays_per_s": n * the_wl.width * the_wl.height / fresh / 1e6}
-        fc = fresh_leg(wl, scene, wl.name)
-        fc["note"] = ("every timed frame has a camera the library has not seen: per-frame host set-up (libm, spherical "
-                      "sin/cos tables on the host pool, upload) inside the loop; then the same cameras from the cache")
-        extra["value_moving_camera"] = fc["value"]
-        if wl.map_size == 4096 and wl.content == "smooth" and wl.name != "C5":
-            fc["C5"] = fresh_leg(synth.WORKLOADS["C5"], scene, "C5")  # (perspective; same maps and scene parameters)
-        secondary["fresh_camera"] = fc
+        def blk_fresh():
+            fc = fresh_leg(wl, scene, wl.name)
+            fc["note"] = ("every timed frame has a camera the library has not seen: per-frame host set-up (libm, spherical "
+                          "sin/cos tables on the host pool, upload) inside the loop; then the same cameras from the cache")
+            extra["value_moving_camera"] = fc["value"]
+            if wl.map_size == 4096 and wl.content == "smooth" and wl.name != "C5":
+                fc["C5"] = fresh_leg(synth.WORKLOADS["C5"], scene, "C5")  # (perspective; same maps and scene parameters)
+            secondary["fresh_camera"] = fc
+        guarded("fresh_camera", blk_fresh)
 
         # ---- the kernel that executes every one of the reference's loads, on the headline frame: the one kernel
         # SURVEY 8(d)'s algorithmic-bytes fraction is defined for
-        def literal():
-            scene.bench_kernel_ms(cam, 2)
-            return scene.bench_kernel_ms(cam, 3)
-        lit_ms = with_kernel("simple", literal)
-        lit_pmc, lit_prov = _pmc_from_profiles(wl.name + "_literal", hmrm.kernel_src_sha())
-        lit_traffic = lit_pmc.get("hbm_bytes_per_launch") if lit_pmc else None
-        secondary["literal_kernel"] = {
-            "kernel": "k_render (HMRM_KERNEL=simple): main/hmap.cpp:1000-1038 as written, one dependent 8-byte load per ray-step",
-            "launches": 3, "kernel_ms": lit_ms, "value": frame_steps / (lit_ms * 1e-3), "unit": "ray-steps/s (executed, not equivalent)",
-            "production_speedup": lit_ms / kernel_ms,
-            "roofline": {"bound": "hbm", "achieved": algo_bytes / (lit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": algo_bytes / (lit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
-                         "traffic": lit_traffic,
-                         "traffic_over_algorithmic": (lit_traffic / algo_bytes) if lit_traffic else None, "pmc": lit_prov}}
+        def blk_literal():
+            def literal():
+                scene.bench_kernel_ms(cam, 2)
+                return scene.bench_kernel_ms(cam, 3)
+            lit_ms = with_kernel("simple", literal)
+            lit_pmc, lit_prov = _pmc_from_profiles(wl.name + "_literal", hmrm.kernel_src_sha())
+            lit_traffic = lit_pmc.get("hbm_bytes_per_launch") if lit_pmc else None
+            secondary["literal_kernel"] = {
+                "kernel": "k_render (HMRM_KERNEL=simple): main/hmap.cpp:1000-1038 as written, one dependent 8-byte load per ray-step",
+                "launches": 3, "kernel_ms": lit_ms, "value": frame_steps / (lit_ms * 1e-3), "unit": "ray-steps/s (executed, not equivalent)",
+                "production_speedup": lit_ms / kernel_ms,
+                "roofline": {"bound": "hbm", "achieved": algo_bytes / (lit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": algo_bytes / (lit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
+                             "traffic": lit_traffic,
+                             "traffic_over_algorithmic": (lit_traffic / algo_bytes) if lit_traffic else None, "pmc": lit_prov}}
+        guarded("literal_kernel", blk_literal)
 
         # ---- the other BASELINE configurations on this GPU
         n_w = max(5, min(args.steps, 50))
         blocks = {}
-        if wl.name == "C3":
-            blocks["C3h"] = workload_block(synth.WORKLOADS["C3h"], scene, n_w, 5)
-            blocks["C5"] = workload_block(synth.WORKLOADS["C5"], scene, n_w, 5)
-            w2 = synth.WORKLOADS["C2"]
-            scene2 = hmrm.Scene(*maps_of(w2), w2.scene_params())
-            blocks["C2"] = workload_block(w2, scene2, n_w, 5)
-            scene2.close()
         secondary["workloads"] = blocks
 
-        # ---- maps built to defeat the traversal: production kernel against the plain 4-step groups
-        if not args.no_rough and wl.content == "smooth":
+        def blk_workloads():
+            if wl.name == "C3":
+                blocks["C3h"] = workload_block(synth.WORKLOADS["C3h"], scene, n_w, 5)
+                blocks["C5"] = workload_block(synth.WORKLOADS["C5"], scene, n_w, 5)
+                w2 = synth.WORKLOADS["C2"]
+                scene2 = hmrm.Scene(*maps_of(w2), w2.scene_params())
+                blocks["C2"] = workload_block(w2, scene2, n_w, 5)
+                scene2.close()
+        guarded("workloads", blk_workloads)
+
+        # ---- maps built to defeat the traversal: the library as shipped against the plain 4-step groups
+        def blk_rough():
             rough = {}
             n_r = max(3, min(args.steps, 10))
             for kind in ("white", "spikes", "needles", "canyon"):
@@ -733,13 +751,17 @@ def main(argv=None):
                              f"(HIP events, {n_r} launches): the production kernel unless the scene's one-time probe measured the plain "
                              "groups at least 3 % faster; group_kernel_ms = HMRM_KERNEL=group (speculative 4-step groups, no leaps)")
             secondary["rough_terrain"] = rough
+        if not args.no_rough and wl.content == "smooth":
+            guarded("rough_terrain", blk_rough)
 
         # ---- C4 on one GPU (8192^2 maps: the scene of the headline is released first)
-        if not args.no_c4 and wl.name == "C3":
+        def blk_c4():
             w4 = synth.WORKLOADS["C4"]
             scene4 = hmrm.Scene(*w4.maps(), w4.scene_params())
             blocks["C4"] = workload_block(w4, scene4, max(5, min(args.steps, 20)), 3)
             scene4.close()
+        if not args.no_c4 and wl.name == "C3":
+            guarded("workloads.C4", blk_c4)
         torch.cuda.synchronize()
     elif not args.no_secondary and multi and args.mode == "frames":
         # ---- the N = 1 line's own step on every GPU (C3's static pose, one stream): comparable with that line's `value`

@@ -63,6 +63,12 @@ int main(int argc, char **argv) {
 	CHECK(rc == HMRM_OK || rc == HMRM_E_DEVICE);
 	if (rc == HMRM_OK) hmrm_scene_destroy(scene);
 	CHECK(hmrm_orbit_frame_owner(10, 8) == 2);
+	{ /* the pyramid layout rule needs no GPU: a 4096^2 map fits the kernel's 32-bit look-up offsets, 16385 x 32766 does not */
+		int32_t row = 0, shift = 0, levels = 0;
+		CHECK(hmrm_debug_mip_layout(4096, 4096, &row, &shift, &levels) == 1 && row == 2048 && shift == 22 && levels == 7);
+		CHECK(hmrm_debug_mip_layout(16385, 32766, &row, &shift, &levels) == 0 && shift == 28);
+		CHECK(hmrm_debug_mip_layout(0, 1, NULL, NULL, NULL) < 0);
+	}
 	hmrm_config_destroy(cfg);
 	printf("abi_smoke ok\n");
 	return 0;

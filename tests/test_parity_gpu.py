@@ -255,6 +255,46 @@ def test_hostile_content_full_frames_match_oracle(gpu, oracle, kind):
     scene.close()
 
 
+def test_kernel_probe_never_changes_a_pixel(gpu, oracle):
+    """The scene's one-time kernel probe (api.cpp launch_frame: the launch-order calibration of the first repeatedly
+    rendered camera also times the plain-groups kernel and the scene keeps the faster one): every frame of the sequence
+    that carries the probe -- before it, the measured launches of either kernel, after the verdict -- equals the oracle's,
+    on a map where the groups win (needles under C5's camera) and on one where the leaps win; HMRM_TRY_GROUP=0 keeps
+    the production kernel; a height update forgets the verdict."""
+    for kind, expect in (("needles", None), ("smooth", 0)):
+        wl = gpu.synth.content_workload("C2", kind) if kind != "smooth" else gpu.synth.WORKLOADS["C2"]
+        rgb, cmap = wl.maps()
+        params, cam = wl.scene_params(), wl.camera()
+        heights = oracle.update_heightmap(rgb, params)
+        ofb, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap)
+        scene = gpu.Scene(rgb, cmap, params)
+        assert scene.kernel_choice() == 0
+        for k in range(16):  # (first launch, 2 x up to 4 measured trials, settled launches)
+            assert np.array_equal(scene.render(cam), ofb), (kind, k)
+        choice = scene.kernel_choice()
+        print(f"{kind}: the probe chose {('the production kernel', 'the plain groups')[choice]}")
+        assert choice in (0, 1) and (expect is None or choice == expect)
+        # another camera of the same scene renders with the scene's verdict: still the oracle's pixels
+        cam2 = wl.camera(5, 64)
+        ofb2, *_ = oracle.render(oracle.make_cfg(cam2, params, wl.map_size, wl.map_size), heights, cmap)
+        assert np.array_equal(scene.render(cam2), ofb2)
+        # strips too
+        import torch
+        strip = torch.zeros((cam.height, cam.width, 4), dtype=torch.uint8, device="cuda")
+        scene.render_rows_device(cam, strip.data_ptr(), cam.width * 4, 100, 300, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(strip.cpu().numpy()[:200], ofb[100:300])
+        scene.update(params)  # (same parameters: the heights are recomputed, the verdict is forgotten)
+        assert scene.kernel_choice() == 0 and np.array_equal(scene.render(cam), ofb)
+        scene.close()
+        with env(HMRM_TRY_GROUP=0):
+            scene = gpu.Scene(rgb, cmap, params)
+            for k in range(12):
+                assert np.array_equal(scene.render(cam), ofb)
+            assert scene.kernel_choice() == 0
+            scene.close()
+
+
 def test_step_cap_is_reported_not_silent(gpu, oracle):
     """A vertical upward ray over a non-hitting cell never leaves the reference's while(true)
     (hmap.cpp:1000-1038).  The kernel stops at the cap, shades a miss and says so."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 profile round on the GPU box (via gpurun): the bench line, the rocprofv3 kernel trace + stats of the headline
 # loop, separate PMC passes (counters only with --kernel-trace) for C3, C3h and -- fetch / write only -- the literal
-# kernel on C3.  Summarise afterwards, here:
+# kernel on C3 (WLS="C3 C3h C5 C2 C4" for more workloads).  Summarise afterwards, here:
 #   python tools/pmc_summary.py gpurun_out/prof_r04_C3 C3 profiles/r04_C3_rocprof      (likewise C3h, C3_literal)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -9,10 +9,10 @@ pmc() { # <outdir> <workload> <variant> <launches> <counters...>
 	d=$1; wl=$2; v=$3; n=$4; shift 4
 	rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$d" -- python tools/prof_run.py $wl $v $n > /dev/null 2>&1
 }
-for WL in C3 C3h; do
+for WL in ${WLS:-C3 C3h}; do
 	out=gpurun_out/prof_r04_$WL
 	rm -rf "$out"; mkdir -p "$out"
-	rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --workload $WL --no-cpu-baseline --no-secondary > "$out/bench_under_rocprof.log" 2>&1
+	rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py --workload $WL --no-cpu-baseline --no-secondary --steps ${STEPS:-200} > "$out/bench_under_rocprof.log" 2>&1
 	pmc "$out/fetch" $WL leap 30 FETCH_SIZE TCC_HIT_sum
 	pmc "$out/write" $WL leap 30 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
 	pmc "$out/sq" $WL leap 30 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
