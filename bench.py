@@ -818,6 +818,10 @@ def main(argv=None):
                           ("counter-separable classes priced, the rest at 2.3 cycles (lower bound)" if busy_lower else None),
             "frac_lower_bound": (busy_lower / kernel_s / 1e9 / peak) if busy_lower else None,
             "frac_if_every_valu_held_the_pipe_4_cycles": (busy_upper / kernel_s / 1e9 / peak) if busy_upper else None,  # = VALUBusy
+            # the same fraction with numerator AND denominator from the profile round's box (rocprofv3's mean launch duration
+            # of that run): boxes of the pool differ by +-3 %, `frac` mixes this run's kernel_ms with that box's counters
+            "frac_on_the_profiled_box": (busy / ((pmc or {}).get("kernel_us_per_frame_rocprof") * 1e-6) / 1e9 / peak)
+                                        if busy and (pmc or {}).get("kernel_us_per_frame_rocprof") else None,
             "traffic": traffic,
             "hbm": {"achieved": (traffic / kernel_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None},
