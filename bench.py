@@ -560,10 +560,15 @@ def main(argv=None):
         c = w.camera()
         fb, s_, _, _ = the_scene.render_stats(c)
         precondition(the_scene, c)
+        # (the shorter of two repetitions: these legs are a few milliseconds long, and a single host hiccup -- one was seen: 58 ms
+        # inside a 3 ms leg -- would otherwise be the number)
         dt, check = static_leg(the_scene, c, n_frames, n_warm, 1, fb)
+        dt_b, check_b = static_leg(the_scene, c, n_frames, n_warm, 1, fb)
+        dt = min(dt, dt_b)
         kms = the_scene.bench_kernel_ms(c, min(50, max(10, n_frames)))  # (straight behind the timed launches: same clocks)
         check()
-        return {"workload": workload_text(w), "frames": n_frames, "ms_per_step": dt * 1e3 / n_frames, "kernel_ms": kms,
+        check_b()
+        return {"workload": workload_text(w), "frames": n_frames, "ms_per_step": dt * 1e3 / n_frames, "repetitions": 2, "kernel_ms": kms,
                 "value": int(s_.steps) * n_frames / dt, "unit": "ray-steps/s", "equivalent_steps": True,
                 "mrays_per_s": int(s_.rays) * n_frames / dt / 1e6, "ray_steps_per_frame": int(s_.steps),
                 "rays_per_frame": int(s_.rays), "hits_per_frame": int(s_.hits), "executed_per_frame": executed(s_)}
