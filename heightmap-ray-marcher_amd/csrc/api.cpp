@@ -107,6 +107,7 @@ using hmrm::kCostRows;
 constexpr int kFrameSlots = 64;  // cached per-frame records (and spherical tables) per stream: a 64-frame orbit fits
 constexpr int kOrderSamples = 2;   // measured launches per trial order (one launch's makespan wobbles by a few per cent)
 constexpr int kMaxMeasRows = 512;  // tile rows (8192 frame rows) a launch order is calibrated for; taller frames keep the rotation
+constexpr int kProbeAfterFrames = 6; // full frames of never-repeating cameras before the scene's shadow probe
 constexpr int kMaxStreamCtx = 32; // streams a scene keeps launch state for (more: the least recently used one is recycled, with a stream sync)
 
 // One cached per-frame record: the result of the host set-up (camera.cpp) for one camera, and for
@@ -161,8 +162,10 @@ struct StreamCtx {
 	unsigned long long *d_meas = nullptr, *h_meas = nullptr, *h_meas_dev = nullptr;
 	FrameSlot *meas_owner = nullptr; // the slot whose measured launch uses d_meas (until its event is done)
 	size_t arena_n = 0; // doubles per slot
-	// [0] steps [1] hits [2] capped rays (cumulative, never reset) [4..7] traversal diagnostics
+	// [0] steps [1] hits [2] capped rays (cumulative, never reset) [4..7] traversal diagnostics; [8..15] the same for the
+	// second launch of a shadow probe (its rays must not be counted twice)
 	unsigned long long *d_counters = nullptr;
+	bool probe_in_flight = false; // the scene's shadow probe uses this context's calibration records
 	unsigned long long capped_seen = 0; // value of [2] the host has already reported
 	// recorded behind every launch: what a recycled context waits for (the caller's stream handle may be gone by then)
 	hipEvent_t last_launch = nullptr;
@@ -250,6 +253,17 @@ struct hmrm_scene {
 	// camera); every other camera -- a moving one is never calibrated -- renders with the kernel that probe chose.
 	bool kernel_probed = false;
 	bool last_settled_group = false;
+	// ... and a scene whose cameras never repeat (a moving camera: nothing is ever calibrated) is probed on its
+	// kProbeAfterFrames-th full frame instead: that frame is launched twice into the same buffer -- production kernel,
+	// then plain groups; same pixels -- both measured like a calibration launch, and the verdict is read when the second
+	// has finished (any later launch looks).  One 3-6 ms hiccup per scene on a 4K frame.
+	uint32_t unprobed_frames = 0;
+	bool probe_pending = false;
+	uint32_t probe_epoch = 0, probe_epoch_launched = 0; // (a height update or a knob reload voids a probe in flight)
+	int probe_rows = 0;
+	StreamCtx *probe_ctx = nullptr;
+	hipEvent_t probe_done = nullptr;
+	unsigned long long *h_probe = nullptr, *h_probe_dev = nullptr; // pinned: 2 x (2 x kMaxMeasRows) words
 	std::vector<SettledOrder> settled;
 };
 
@@ -296,6 +310,7 @@ int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 		// its kernels may still read the tables / counters about to be freed.  The stream belongs to the caller and
 		// may have been destroyed since (no call may name it any more): wait on the context's own event instead
 		(void)hipEventSynchronize(s->ctxs[victim]->last_launch);
+		if (s->probe_ctx == s->ctxs[victim]) s->probe_ctx = nullptr;
 		destroy_ctx(s->ctxs[victim]);
 		s->ctxs.erase(s->ctxs.begin() + (long)victim);
 	}
@@ -305,10 +320,10 @@ int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 	c->scene_owned = stream == s->stream;
 	for (hipStream_t lane : s->lanes) c->scene_owned = c->scene_owned || (lane && stream == lane);
 	c->stamp = ++s->clock;
-	hipError_t e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long));
+	hipError_t e = hipMalloc((void **)&c->d_counters, 16 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_launch, hipEventDisableTiming);
 	// (zeroed on the scene's stream and waited for: the caller's stream may be anything)
-	if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), s->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
 	if (e != hipSuccess) {
 		destroy_ctx(c);
@@ -497,6 +512,18 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 	return HMRM_OK;
 }
 
+// The calibration records of a context: the device buffer of the ONE measured launch it has in flight at a time and, per
+// cached record, kMaxMeasRows x {start, longest wave} in pinned memory (allocated with the first measured launch).
+int ensure_meas(StreamCtx *c) {
+	if (!c->d_meas) HIP_TRY(hipMalloc((void **)&c->d_meas, (size_t)kMaxMeasRows * hmrm::kMeasureStride * sizeof(unsigned long long)));
+	if (!c->h_meas) {
+		const size_t n = (size_t)kFrameSlots * 2 * kMaxMeasRows * sizeof(unsigned long long);
+		HIP_TRY(hipHostMalloc((void **)&c->h_meas, n, hipHostMallocMapped));
+		HIP_TRY(hipHostGetDevicePointer((void **)&c->h_meas_dev, c->h_meas, 0));
+	}
+	return HMRM_OK;
+}
+
 // One frame (or row strip) on the context's stream.  Kernel variant: "leap" (default; speculative
 // groups + exact leaps), "group" (speculative groups only), "simple" (the literal
 // one-step-at-a-time loop, kept for A/B runs and as an in-library cross-check).  All produce
@@ -507,6 +534,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 	bool measure_now = false;
 	int tiles_y = 0, trial_now = -1;
 	bool use_group = false; // render with the plain groups (the calibration measured them faster on this content)
+	bool shadow_probe = false;
 	{
 		int tile_w = 1, tile_h = 1;
 		hmrm::render_tile_shape(&tile_w, &tile_h);
@@ -594,13 +622,60 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 			use_group = s->last_settled_group; // strips, bands, small frames: the scene's last measured choice
 		}
 		hmrm::set_tile_order(&rows_in_order, tiles_y, rot, nb, b, c3);
+		// ---- the scene's shadow probe (cameras that never repeat): verdict of one in flight, start of a new one
+		if (s->probe_pending && hipEventQuery(s->probe_done) == hipSuccess) {
+			s->probe_pending = false;
+			if (s->probe_ctx) s->probe_ctx->probe_in_flight = false;
+			if (s->probe_epoch_launched == s->probe_epoch) {
+				const double leap_span = std::max(1.0, hmrm::measured_makespan(s->h_probe, s->probe_rows));
+				const double group_span = std::max(1.0, hmrm::measured_makespan(s->h_probe + 2 * kMaxMeasRows, s->probe_rows));
+				s->last_settled_group = group_span < 0.97 * leap_span;
+				if (s->knobs.order_verbose)
+					fprintf(stderr, "hmrm probe: production kernel %.1f us, plain groups %.1f us -> %s\n", leap_span / 100.0, group_span / 100.0,
+					        s->last_settled_group ? "plain groups" : "production kernel");
+			}
+		}
+		if (eligible && !measure_now && s->knobs.kernel == 0 && s->knobs.try_group && !s->kernel_probed && !s->probe_pending &&
+		    c->meas_owner == nullptr && slot->trial_in_flight < 0 && ++s->unprobed_frames >= (uint32_t)kProbeAfterFrames)
+			shadow_probe = true;
+	}
+	if (c->probe_in_flight && measure_now) { // (the probe holds this context's device records: this trial waits a launch)
+		measure_now = false;
+		trial_now = -1;
+		use_group = s->last_settled_group;
+	}
+	if (shadow_probe) {
+		if (!s->h_probe) {
+			HIP_TRY(hipHostMalloc((void **)&s->h_probe, (size_t)4 * kMaxMeasRows * sizeof(unsigned long long), hipHostMallocMapped));
+			HIP_TRY(hipHostGetDevicePointer((void **)&s->h_probe_dev, s->h_probe, 0));
+			HIP_TRY(hipEventCreateWithFlags(&s->probe_done, hipEventDisableTiming));
+		}
+		{
+			const int rc_m = ensure_meas(c);
+			if (rc_m) return rc_m;
+		}
+		hmrm::RowMap measured = rows_in_order;
+		measured.measure = c->d_meas;
+		for (int pass = 0; pass < 2; ++pass) { // production kernel, then the plain groups: the same frame into the same buffer
+			HIP_TRY(hmrm::launch_measure_init(measured.measure, tiles_y, c->stream));
+			HIP_TRY(hmrm::launch_render_fast(f, measured, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
+			                                 c->d_counters + (pass ? 8 : 0), nullptr, nullptr, false, pass == 0, c->stream));
+			HIP_TRY(hmrm::launch_measure_readback(measured.measure, s->h_probe_dev + (size_t)pass * 2 * kMaxMeasRows, tiles_y, c->stream));
+		}
+		HIP_TRY(hipEventRecord(s->probe_done, c->stream));
+		s->probe_pending = true;
+		s->kernel_probed = true;
+		s->probe_rows = tiles_y;
+		s->probe_epoch_launched = s->probe_epoch;
+		s->probe_ctx = c;
+		c->probe_in_flight = true;
+		if (!c->scene_owned) HIP_TRY(hipEventRecord(c->last_launch, c->stream));
+		return HMRM_OK;
 	}
 	if (measure_now) {
-		if (!c->d_meas) {
-			HIP_TRY(hipMalloc((void **)&c->d_meas, (size_t)kMaxMeasRows * hmrm::kMeasureStride * sizeof(unsigned long long)));
-			const size_t n = (size_t)kFrameSlots * 2 * kMaxMeasRows * sizeof(unsigned long long);
-			HIP_TRY(hipHostMalloc((void **)&c->h_meas, n, hipHostMallocMapped));
-			HIP_TRY(hipHostGetDevicePointer((void **)&c->h_meas_dev, c->h_meas, 0));
+		{
+			const int rc_m = ensure_meas(c);
+			if (rc_m) return rc_m;
 		}
 		if (!slot->measured) HIP_TRY(hipEventCreateWithFlags(&slot->measured, hipEventDisableTiming));
 		rows_in_order.measure = c->d_meas;
@@ -742,6 +817,8 @@ int run_update_heights(hmrm_scene *s) {
 	s->settled.clear();
 	s->last_settled_group = false; // (new heights: new content)
 	s->kernel_probed = false;
+	s->unprobed_frames = 0;
+	++s->probe_epoch;
 	unsigned long long key = 0;
 	HIP_TRY(hipMemcpyAsync(&key, s->d_maxkey, sizeof key, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -884,6 +961,8 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (s->d_maxkey) (void)hipFree(s->d_maxkey);
 	if (s->d_frame) (void)hipFree(s->d_frame);
 	if (s->h_stage) (void)hipHostFree(s->h_stage);
+	if (s->h_probe) (void)hipHostFree(s->h_probe);
+	if (s->probe_done) (void)hipEventDestroy(s->probe_done);
 	if (s->d_steps) (void)hipFree(s->d_steps);
 	if (s->d_entry) (void)hipFree(s->d_entry);
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -910,6 +989,8 @@ int hmrm_debug_reload_env(hmrm_scene *s) {
 	s->settled.clear();
 	s->last_settled_group = false;
 	s->kernel_probed = false;
+	s->unprobed_frames = 0;
+	++s->probe_epoch;
 	for (StreamCtx *c : s->ctxs)
 		for (FrameSlot &sl : c->slots) {
 			if (sl.trial_in_flight >= 0 && sl.measured) HIP_TRY(hipEventSynchronize(sl.measured)); // (its read-back targets the slot's records)

@@ -261,8 +261,9 @@ int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_
 
 /* Which kernel full frames of this scene are rendered with: 0 = the production kernel (speculative groups + exact
  * leaps), 1 = the speculative groups alone, 2 = the literal loop.  1 without HMRM_KERNEL=group means the scene's
- * one-time probe (part of the launch-order calibration of the first camera that is rendered repeatedly) measured
- * the plain groups at least 3 % faster on this content -- maps on which rays cannot jump. */
+ * one-time probe (part of the launch-order calibration of the first camera that is rendered repeatedly, or -- for
+ * cameras that never repeat -- the scene's sixth full frame launched twice) measured the plain groups at least 3 %
+ * faster on this content -- maps on which rays cannot jump. */
 int hmrm_debug_kernel_choice(const hmrm_scene *scene);
 
 /* The environment knobs (HMRM_KERNEL, HMRM_STEP_CAP, ...) are read once, when a

@@ -295,6 +295,45 @@ def test_kernel_probe_never_changes_a_pixel(gpu, oracle):
             scene.close()
 
 
+def test_shadow_probe_for_cameras_that_never_repeat(gpu, oracle):
+    """A moving camera is never calibrated, so the scene's kernel probe cannot ride on a calibration: the sixth full frame
+    of such a scene is launched twice into the same buffer (production kernel, then plain groups; both measured) and a
+    later launch reads the verdict.  Every frame of the sequence -- before, the doubled one, after -- is the oracle's; a
+    ray stopped by the step cap in the doubled frame is counted once; on a map where rays cannot jump the scene may
+    switch to the groups."""
+    wl = gpu.synth.content_workload("C2", "needles")
+    rgb, cmap = wl.maps()
+    params = wl.scene_params()
+    heights = oracle.update_heightmap(rgb, params)
+    scene = gpu.Scene(rgb, cmap, params)
+    for k in range(14):
+        cam = wl.camera(k, 64)  # (14 different cameras of the orbit: nothing repeats)
+        cam.width, cam.height = 640, 360
+        ofb, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap)
+        assert np.array_equal(scene.render(cam), ofb), k
+    print("needles under a moving camera: the shadow probe chose", ("the production kernel", "the plain groups")[scene.kernel_choice()])
+    assert scene.kernel_choice() in (0, 1)
+    scene.close()
+    # capped rays in the doubled frame are reported once
+    with env(HMRM_STEP_CAP=60):
+        scene = gpu.Scene(rgb, cmap, params)
+        for k in range(9):
+            cam = wl.camera(k, 64)
+            cam.width, cam.height = 640, 360
+            ofb, total, capped, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size, step_cap=60), heights, cmap)
+            fb, st, *_ = scene.render_stats(cam, allow_capped=True)  # (the instrumented count of this frame)
+            assert st.capped == capped and np.array_equal(fb, ofb)
+            try:
+                got = scene.render(cam)
+                n_capped = 0
+            except gpu.HmrmError as e:
+                assert e.code == gpu.HMRM_E_NOTERM
+                n_capped = int(e.message.split()[0])
+                got = None
+            assert n_capped == capped, (k, n_capped, capped)
+        scene.close()
+
+
 def test_step_cap_is_reported_not_silent(gpu, oracle):
     """A vertical upward ray over a non-hitting cell never leaves the reference's while(true)
     (hmap.cpp:1000-1038).  The kernel stops at the cap, shades a miss and says so."""
