@@ -1136,9 +1136,9 @@ def test_c4_eight_rank_band_emulation_full_size(gpu, oracle):
 
 
 # The four slices share ONE time budget (conftest.FUZZ_BUDGET_S, env HMRM_FUZZ_BUDGET_S, default 300 s) in the proportions
-# 150 : 150 : 100 : 60 of round 3's fixed slices.
-_FUZZ_SHARES = (("deep_fuzz.py", 150, []), ("deep_fuzz_big.py", 150, ["4096"]), ("deep_fuzz_edges.py", 100, []),
-                ("deep_fuzz_binades.py", 60, []))
+# 140 : 140 : 90 : 50 : 40 (round 3's four fixed slices were 150 / 150 / 100 / 60 s; round 4 added the cell-boundary fuzzer).
+_FUZZ_SHARES = (("deep_fuzz.py", 140, []), ("deep_fuzz_big.py", 140, ["4096"]), ("deep_fuzz_edges.py", 90, []),
+                ("deep_fuzz_binades.py", 50, []), ("deep_fuzz_cells.py", 40, []))
 
 
 def _fuzz_cases():
@@ -1152,7 +1152,8 @@ def _fuzz_cases():
 def test_deep_fuzz_slice(gpu, script, args):
     """A seeded time-boxed slice of each long fuzzer (tests/deep_fuzz*.py: random maps from 1x1 up, random cameras
     over the 4096^2 map, cameras whose rays graze the box's edges and corners, and long low maps crossed end to end by
-    shallow rays through a dozen binades; all projections and sampling modes, GPU vs oracle on frames, per-ray step
+    shallow rays through a dozen binades, and rays along / onto cell boundaries under general grid widths incl. the ones
+    whose reciprocal is an integer; all projections and sampling modes, GPU vs oracle on frames, per-ray step
     counts, distance() bits and cap counts) inside the suite the driver runs."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
