@@ -15,6 +15,9 @@ relays rank 0's one JSON line and exits with the child's code.  Launched under t
 directly (WORLD_SIZE set: what the driver does) the same file is a rank.  `--dry-launch` runs launcher,
 rendezvous, sharding and the gather on CPU (gloo, a pattern instead of the renderer): the CPU test of
 the launch path (tests/test_bench_launch.py); its line says "dry_launch": true and carries no value.
+`--share-gpu` is the rehearsal of the N > 1 line on a box with fewer GPUs than ranks: the ranks share the GPUs that are
+there, the collectives run over gloo on host copies, every block and pixel check of the line runs
+("share_gpu": true; the rates are no scaling figures).
 
 N = 1: `value` / `ms_per_step` = K frames of the workload's static pose launched BACK TO BACK ON ONE
        STREAM, maps resident in HBM, output to a device buffer -- the operating point `roofline`
@@ -106,6 +109,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-c4", action="store_true", help="skip the blocks that need the 8192^2 maps (workloads.C4, c4_strips)")
     ap.add_argument("--no-rough", action="store_true", help="N = 1: skip the rough_terrain block")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N > 1 line on a box with fewer GPUs than ranks: every rank renders on GPU (local rank mod "
+                         "visible devices), collectives run over gloo on host copies.  Every block and every pixel check of the N > 1 "
+                         "line runs; the rates say nothing about scaling (the line carries \"share_gpu\": true)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="CPU rehearsal of the launch path: gloo instead of RCCL, a pattern instead of the renderer, no GPU touched")
     return ap.parse_args(argv)
@@ -152,7 +159,8 @@ class Job:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dry = args.dry_launch
-        self.device = "cpu" if self.dry else "cuda"
+        self.share_gpu = args.share_gpu and not args.dry_launch
+        self.device = "cpu" if (self.dry or self.share_gpu) else "cuda"  # where the tensors of the collectives live
         # HMRM_FORCE_DIST=1 runs the torch.distributed (RCCL) code path even with one rank, so that
         # the N>1 plumbing can be exercised on a single-GPU box
         self.multi = self.world > 1 or os.environ.get("HMRM_FORCE_DIST", "") == "1"
@@ -164,9 +172,9 @@ class Job:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if self.dry:
+        if self.dry or self.share_gpu:
             dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            me = torch.tensor([_host_id(), self.rank, 0], dtype=torch.int64)
+            me = torch.tensor([_host_id(), torch.cuda.current_device() if self.share_gpu else self.rank, 0], dtype=torch.int64)
         else:
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
                                     device_id=torch.device("cuda", self.local_rank))
@@ -384,10 +392,10 @@ def main(argv=None):
     n_dev = hmrm.device_count() if torch.cuda.is_available() else 0
     if n_dev < 1:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if job.local_rank >= n_dev:
+    if job.local_rank >= n_dev and not job.share_gpu:
         raise SystemExit(f"bench.py: rank {rank} has no GPU of its own (local rank {job.local_rank}, {n_dev} device(s) visible)")
-    torch.cuda.set_device(job.local_rank)
-    hmrm.set_device(job.local_rank)
+    torch.cuda.set_device(job.local_rank % n_dev)
+    hmrm.set_device(job.local_rank % n_dev)
     multi = job.multi
     if multi:
         job.init_dist()
@@ -496,6 +504,18 @@ def main(argv=None):
         del keep
         return dt, total_over_ranks(sum(steps_of[k] for k in mine[n_warm:])), check
 
+    def frame_over_ranks(plan, the_rank, render_rows_fn, dist_or_none, strip, block):
+        """strips.render_frame_distributed; under --share-gpu the gather runs over gloo on host copies of the strips."""
+        if dist_or_none is None or not job.share_gpu:
+            return strips.render_frame_distributed(plan, the_rank, render_rows_fn, dist_or_none, strip, block)
+        render_rows_fn(strip, plan.band_rows, the_rank, plan.world)
+        host = strip.cpu()
+        parts = [torch.empty_like(host) for _ in range(plan.world)] if the_rank == 0 else None
+        dist_or_none.gather(host, gather_list=parts, dst=0)
+        if the_rank != 0:
+            return None
+        return strips.reassemble_torch(plan, torch.stack(parts, 0))
+
     def strips_block(the_wl, the_scene, n_frames):
         """ONE frame of the_wl in cyclic 16-row bands over the ranks (BASELINE configs[3]'s sharding): kernel only, strips
         gathered to rank 0 over RCCL, every rank's strip to its own pinned host memory; and the same three on ONE GPU
@@ -519,7 +539,7 @@ def main(argv=None):
                 render_rows4(strip, plan.band_rows, the_rank, plan.world)
 
             def step_gather():
-                result["frame4"] = strips.render_frame_distributed(plan, the_rank, render_rows4, job.dist if plan.world > 1 else None, strip, block)
+                result["frame4"] = frame_over_ranks(plan, the_rank, render_rows4, job.dist if plan.world > 1 else None, strip, block)
 
             def step_own():
                 strips.render_strip_to_host(plan, the_rank, render_rows4, strip, host_strip)
@@ -623,7 +643,7 @@ def main(argv=None):
                                      band_index=band_index, band_count=band_count, stream=stream)
 
         def step():
-            result["frame"] = strips.render_frame_distributed(plan, rank, render_rows, job.dist, strip, block)
+            result["frame"] = frame_over_ranks(plan, rank, render_rows, job.dist, strip, block)
         for _ in range(args.warmup):
             step()
         elapsed = timed(step, args.steps)
@@ -870,6 +890,8 @@ def main(argv=None):
             "roofline": roofline,
         }
         line.update(extra)
+        if job.share_gpu:
+            line["share_gpu"] = True  # (a rehearsal: ranks share GPUs, collectives over gloo on host copies; not a scaling figure)
         if job.rccl_ranks is not None:
             line["rccl_ranks"] = job.rccl_ranks
         line.update(secondary)

@@ -994,6 +994,34 @@ def test_rows_device_reports_capped_rays(gpu):
         scene.close()
 
 
+def test_bench_two_ranks_sharing_this_gpu(gpu):
+    """The N > 1 line of bench.py with TWO ranks for real -- its own launcher, torch.distributed rendezvous, the orbit leg
+    sharded frame k -> rank k mod 2, the one-GPU reference leg where rank 1 only stands in the barriers, every pixel check --
+    on this one-GPU box: `--share-gpu` lets both ranks render on the same device and runs the collectives over gloo on host
+    copies.  (No 8-GPU node has been available in any round; this is the nearest thing to a run of that code path.)"""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env2 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HMRM_FORCE_DIST")}
+    env2["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "C2", "--steps", "6",
+                        "--warmup", "2", "--no-c4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["share_gpu"] is True and line["scaling"] == "weak"
+    assert line["rccl_ranks"]["world_size"] == 2 and line["rccl_ranks"]["backend"] == "gloo"
+    assert line["value"] > 0 and line["one_gpu_same_leg"]["value"] > 0 and 0.2 < line["efficiency_vs_one_gpu"] < 1.5
+    assert "C2" in line["config"]["workload"] and "frame k on GPU k mod 2" in line["config"]["parallelism"]
+    # the strips mode: one frame in cyclic bands over the two ranks, gathered to rank 0 and checked there
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "C2", "--mode", "strips",
+                        "--steps", "4", "--warmup", "1", "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["scaling"] == "strong" and "cyclic 16-row bands over 2 GPUs" in line["config"]["parallelism"]
+
+
 def test_strips_over_rccl_two_gpus(gpu):
     """bench.py --mode strips on two GPUs over RCCL (C2: cyclic 16-row bands, gather to rank 0, frame
     checked against the single-GPU frame inside bench.py).  Skips on a one-GPU box."""
