@@ -85,9 +85,6 @@ constexpr bool kAdaptive = kAdaptAfter > 0;
 #define HMRM_EARLY_LOAD 1
 #endif
 constexpr bool kEarlyLoad = HMRM_EARLY_LOAD != 0;
-#ifndef HMRM_PREFETCH
-#define HMRM_PREFETCH 0
-#endif
 
 // ---- bilinear quality mode (HMRM_BILINEAR; a build-side addition, not in the reference) ----
 // Same definition, operation for operation, as oracle/hmrm_oracle.c "bilinear quality mode":
@@ -290,19 +287,6 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						iy = iy < 0 ? 0 : iy;
 						const unsigned widx = ((unsigned)lev << f.mip_plane_shift) + (unsigned)index_2d(iy, f.mip_row, ix); // (= mip_index)
 						diag.load_begin(f, 17);
-#if HMRM_PREFETCH
-						// Speculative prefetch (HMRM_PREFETCH): the window one window-height further along the ray's y direction, same
-						// level -- another cache line of the plane (x neighbours share the line being fetched anyway).  Issued in
-						// front of the real look-up, never used: it only warms the L2 for the attempt after a crossing.
-						float pf;
-						{
-							const int adv = (sparse ? 2 : 4) * (offy ? -1 : 1);
-							const int piy = iy + adv;
-							const bool pin = inb0 && !top && piy >= 0 && piy < ((f.map_h + (1 << hs) - 1) >> hs); // (rows of this level's plane)
-							const unsigned pidx = ((unsigned)lev << f.mip_plane_shift) + (unsigned)index_2d(pin ? piy : iy, f.mip_row, ix);
-							pf = *(const float *)((const char *)mip + (size_t)((inb0 ? pidx : 0u) * 4u));
-						}
-#endif
 						// (a 32-bit byte offset from the pyramid's base: at most 8 planes of 2^27 floats, api.cpp's map limit)
 						float mf = *(const float *)((const char *)mip + (size_t)((inb0 ? widx : 0u) * 4u));
 						diag.load_end(f, 17, mf);
@@ -329,9 +313,6 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 							if (kEarlyLoad) asm volatile("" : "+v"(mf) : "v"(room_lat));
 						}
 						const double m = (double)mf; // (floats rounded up: also bounds every float / interpolated threshold)
-#if HMRM_PREFETCH
-						asm volatile("" : : "v"(pf));
-#endif
 						const bool above = z >= m;
 						// Nothing below can succeed unless the ray is above this window's maximum: when no
 						// lane of the wave is, skip the estimate and the verification (the usual case in
