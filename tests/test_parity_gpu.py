@@ -1012,7 +1012,8 @@ def test_bench_two_ranks_sharing_this_gpu(gpu):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["share_gpu"] is True and line["scaling"] == "weak"
     assert line["rccl_ranks"]["world_size"] == 2 and line["rccl_ranks"]["backend"] == "gloo"
-    assert line["value"] > 0 and line["one_gpu_same_leg"]["value"] > 0 and 0.2 < line["efficiency_vs_one_gpu"] < 1.5
+    # (no bound on the efficiency: two processes time-slicing one GPU say nothing about scaling, only that the legs ran)
+    assert line["value"] > 0 and line["one_gpu_same_leg"]["value"] > 0 and line["efficiency_vs_one_gpu"] > 0
     assert "C2" in line["config"]["workload"] and "frame k on GPU k mod 2" in line["config"]["parallelism"]
     # the strips mode: one frame in cyclic bands over the two ranks, gathered to rank 0 and checked there
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "C2", "--mode", "strips",
