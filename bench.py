@@ -42,7 +42,8 @@ N = 1: `value` / `ms_per_step` = K frames of the workload's static pose launched
                            altitude): the library as shipped against the plain 4-step groups.
 N > 1: one process per GPU over RCCL, maps replicated.  `value` = frames of BASELINE configs[4]'s
        64-frame orbit ("C5"; `--workload` overrides), frame k on GPU k mod N, K frames per GPU on one
-       stream each, no data-path collective, scaling "weak".  The same line carries `rccl_ranks`
+       stream each, no data-path collective, scaling "weak" (`per_rank_ms_per_step`: every rank's own time; `ms_per_step` is
+       their maximum).  The same line carries `rccl_ranks`
        (distinct (host, device, bus) triples seen by an all_gather), `one_gpu_same_leg` (rank 0 alone
        rendering K frames of the same orbit in the same run) with the speed-up and efficiency against
        it, `static_pose_replicas` (the N = 1 line's own step on every GPU: comparable with that line's
@@ -166,6 +167,7 @@ class Job:
         self.multi = self.world > 1 or os.environ.get("HMRM_FORCE_DIST", "") == "1"
         self.dist = None
         self.rccl_ranks = None
+        self.last_rank_seconds = []
 
     def init_dist(self):
         torch = self.torch
@@ -205,10 +207,14 @@ class Job:
             step()
         self.barrier()
         dt = time.perf_counter() - t0
+        self.last_rank_seconds = [dt]
         if self.dist is not None:
+            # every rank's own time (the contract's figure is their maximum; the list shows a straggler when there is one)
             t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.device)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            dt = float(t.item())
+            every = [self.torch.zeros_like(t) for _ in range(self.world)]
+            self.dist.all_gather(every, t)
+            self.last_rank_seconds = [float(v.item()) for v in every]
+            dt = max(self.last_rank_seconds)
         return dt
 
     def total(self, v):
@@ -620,6 +626,7 @@ def main(argv=None):
                       f"1 GPU, {in_flight} frames in flight on {in_flight} HIP streams"
     elif args.mode == "frames":
         elapsed, total_steps_timed, check_orbit = orbit_leg(wl, scene, args.steps, args.warmup, in_flight)
+        extra["per_rank_ms_per_step"] = [round(v * 1e3 / args.steps, 5) for v in job.last_rank_seconds]
         check_orbit()
         check_headline = lambda: None  # noqa: E731
         rays_timed = frame_rays * args.steps * world
