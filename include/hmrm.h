@@ -164,13 +164,13 @@ int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_ca
  * scene; the ring grows on demand and is freed with the scene.
  * Consecutive frames go to three scene-owned launch streams in turn: with two or more tickets in flight the
  * tail of one launch (a few long waves) also overlaps the start of the next (small frames: 1080p over a 1024^2 map
- * 0.064 -> 0.045 ms of GPU time per frame) -- the caller manages no stream. */
+ * 0.064 -> 0.042 ms of GPU time per frame, profiles/r04_lanes.txt) -- the caller manages no stream. */
 int  hmrm_render_begin(const hmrm_scene *scene, const hmrm_camera *cam, int32_t *ticket);
 int  hmrm_render_wait(const hmrm_scene *scene, int32_t ticket, const uint8_t **rgba, size_t *stride_bytes);
 void hmrm_render_release(const hmrm_scene *scene, int32_t ticket);
 
-/* The same for a frame that stays on the GPU (a sequence of frames consumed there: an encoder, a compositor, a
- * collective): hmrm_render_device_begin launches the frame into the caller's DEVICE memory d_rgba (width x height
+/* The same pass of main/hmap.cpp:978-1058 for a frame that stays on the GPU (a sequence of frames consumed there -- an
+ * encoder, a compositor, a collective -- in place of the blit at hmap.cpp:1082): hmrm_render_device_begin launches the frame into the caller's DEVICE memory d_rgba (width x height
  * RGBA8, stride_bytes a multiple of 4) on the next of the scene's launch streams and returns a ticket;
  * hmrm_render_device_wait blocks until that frame is complete (HMRM_E_NOTERM like hmrm_render; the ticket is
  * free again either way).  Frames in flight must not share memory.  Up to 64 in flight per scene. */
