@@ -546,7 +546,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 		// calibration (see plan_order_from_measurement): full frames of the production kernel only
 		const bool eligible = !pieces && !stats && s->knobs.tile_order && s->knobs.order_mode == 2 && s->knobs.kernel != 2 &&
 		                      rows.band_rows == 0 && rows.row_begin == 0 && rows.local_rows == f.screen_h && tiles_y >= 12 &&
-		                      tiles_y <= kMaxMeasRows && s->map_w < (1 << 24) && s->map_h < (1 << 24);
+		                      tiles_y <= kMaxMeasRows && s->map_w < (1 << 24) && s->map_h < (1 << 24) && s->mip_offsets_fit;
 		if (eligible) {
 			++slot->uses;
 			const size_t idx = (size_t)(slot - c->slots);
@@ -800,6 +800,12 @@ int ensure_bilinear_pyramid(hmrm_scene *s) {
 // between frames, hmap.cpp:517-519).
 int run_update_heights(hmrm_scene *s) {
 	const int64_t n = (int64_t)s->map_w * s->map_h;
+	// The ticketed entry points launch on the scene's lanes, not on s->stream: frames still in flight there (and ring
+	// frames the copy stream has not delivered yet) read the tables about to be rewritten.  Drain every stream the
+	// scene owns first; s->stream itself is ordered by the stream.  (Callers' own streams: their business, hmrm.h.)
+	for (StreamCtx *c : s->ctxs)
+		if (c->scene_owned && c->stream != s->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+	if (s->copy_stream) HIP_TRY(hipStreamSynchronize(s->copy_stream));
 	HIP_TRY(hipMemsetAsync(s->d_maxkey, 0, sizeof(unsigned long long), s->stream));
 	HIP_TRY(hmrm::launch_prepare_heights(s->d_rgb, s->d_thr, n, s->params.lum_r, s->params.lum_g,
 	                                     s->params.lum_b, s->params.min_height, s->params.max_height,
@@ -1177,8 +1183,12 @@ int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_ca
 	// fails with hipErrorInvalidValue, which is not an error of this call)
 	bool pinned_dst = false;
 	{
-		hipPointerAttribute_t attr{};
-		if (hipPointerGetAttributes(&attr, rgba) == hipSuccess) pinned_dst = attr.type == hipMemoryTypeHost;
+		// (first AND last byte: a frame only partly inside a registered block would send the later bands' copies
+		// through the runtime's staging, which blocks the calling thread per band)
+		hipPointerAttribute_t attr{}, attr_end{};
+		const uint8_t *last = rgba + (size_t)(H - 1) * stride_bytes + W * 4 - 1;
+		if (hipPointerGetAttributes(&attr, rgba) == hipSuccess && hipPointerGetAttributes(&attr_end, last) == hipSuccess)
+			pinned_dst = attr.type == hipMemoryTypeHost && attr_end.type == hipMemoryTypeHost;
 		else (void)hipGetLastError();
 	}
 	int launched = 0; // scenes with work in flight: drained before an error return (the caller may free `rgba` at once)

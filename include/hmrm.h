@@ -23,8 +23,10 @@
  * set-up of a call is serialised per scene.  The
  * entry points that return pixels in host memory (hmrm_render, _stats, _cycle, _multi) use the scene's own
  * stream and scratch frame: one such call at a time per scene.  hmrm_render_begin may be called while
- * other tickets are in flight.  hmrm_scene_update and hmrm_scene_destroy require that no launch of that
- * scene is in flight on a caller's stream.  hmrm_last_error() is per thread.
+ * other tickets are in flight.  hmrm_scene_update waits for every frame in flight on the scene's OWN streams
+ * (tickets of hmrm_render_begin / hmrm_render_device_begin included: they finish with the old heights) before it
+ * rewrites the tables; it and hmrm_scene_destroy require that no launch of that scene is in flight on a
+ * CALLER's stream (hmrm_render_rows_device).  hmrm_last_error() is per thread.
  */
 #ifndef HMRM_H
 #define HMRM_H

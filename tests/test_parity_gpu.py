@@ -783,6 +783,47 @@ def test_device_tickets_and_launch_lanes(gpu, oracle):
     scene.close()
 
 
+def test_scene_update_with_tickets_in_flight(gpu, oracle):
+    """hmrm_scene_update while frames are in flight on the scene's launch lanes: the update drains the
+    lanes and the ring's copy stream before it rewrites the threshold table and the pyramid, so every ticket begun
+    before it finishes with the OLD heights -- never a torn mix of old thresholds and new window maxima -- and every
+    frame begun after it sees the new ones.  Slow frames on purpose (the literal loop over a 512^2 map) so that the
+    update really arrives while they run."""
+    import torch
+    rgb, cmap = gpu.synth.synth_maps(512)
+    p_old = gpu.SceneParams.make(0.0, 40.0, grid_width=1.0)
+    p_new = gpu.SceneParams.make(5.0, 90.0, lum=(0.2, 0.7, 0.1), grid_width=1.0)
+    cam = gpu.Camera.make(width=480, height=270, projection=1, hfov=gpu.degrees_to_rads(90), hang=gpu.degrees_to_rads(-45),
+                          vang=gpu.degrees_to_rads(115), pos=(-64.0, 64.0, 128.0), step_dist=0.25, bg=(1, 2, 3))
+    want = {}
+    for key, p in (("old", p_old), ("new", p_new)):
+        heights = oracle.update_heightmap(rgb, p)
+        want[key] = oracle.render(oracle.make_cfg(cam, p, 512, 512), heights, cmap)[0]
+    assert not np.array_equal(want["old"], want["new"])
+    for variant in ("simple", "leap"):
+        with kernel_variant(variant):
+            scene = gpu.Scene(rgb, cmap, p_old)
+            for lap in range(3):
+                scene.update(p_old)
+                dev = [torch.zeros((270, 480, 4), dtype=torch.uint8, device="cuda") for _ in range(6)]
+                tickets = [scene.render_device_begin(cam, b.data_ptr(), 480 * 4) for b in dev]
+                ring = [scene.render_begin(cam) for _ in range(3)]
+                scene.update(p_new)  # (frames of both kinds still in flight)
+                after = torch.zeros((270, 480, 4), dtype=torch.uint8, device="cuda")
+                t_after = scene.render_device_begin(cam, after.data_ptr(), 480 * 4)
+                for t in tickets:
+                    scene.render_device_wait(t)
+                for b in dev:
+                    assert np.array_equal(b.cpu().numpy(), want["old"]), (variant, lap)
+                for t in ring:
+                    assert np.array_equal(scene.render_wait(t, (270, 480)), want["old"]), (variant, lap)
+                    scene.render_release(t)
+                scene.render_device_wait(t_after)
+                assert np.array_equal(after.cpu().numpy(), want["new"]), (variant, lap)
+                assert np.array_equal(scene.render(cam), want["new"])
+            scene.close()
+
+
 def test_recording_sharded_over_scenes(gpu, oracle, tmp_path):
     """hmrm_record_orbit_multi (BASELINE config C5: frame k on GPU k mod N): with one scene per
     "device" (here two or three scenes on the one GPU of the box) the files are byte for byte those of
