@@ -18,7 +18,6 @@ struct LoopDiag<false> {
 	__device__ __forceinline__ void on_landing_refused(const DevFrame &, bool, bool, bool, bool) {}
 	__device__ __forceinline__ void on_attempt_done(const DevFrame &, bool, bool, bool, bool, bool, bool, bool, int, int) {}
 	__device__ __forceinline__ void on_trip(const DevFrame &, bool, bool) {}
-	__device__ __forceinline__ void on_extra_leg(bool, int) {}
 	__device__ __forceinline__ void on_bounds(bool, bool) {}
 	__device__ __forceinline__ void on_group() {}
 	__device__ __forceinline__ void load_begin(const DevFrame &, int) {}
@@ -107,8 +106,6 @@ struct LoopDiag<true> {
 		leaped += ok ? (unsigned)n : 0u;
 		leaps += ok ? 1u : 0u;
 	}
-	// a further leg of a chained jump (its steps are in the n the attempt reports)
-	__device__ __forceinline__ void on_extra_leg(bool ok, int) { leaps += ok ? 1u : 0u; }
 	// modes 12-15: wave-level view of the loop -- who runs which block, with how many useful lanes
 	__device__ __forceinline__ void on_trip(const DevFrame &f, bool leap_enabled, bool skip_group) {
 		if (f.diag_mode == 20 && !skip_group) { // mode 20: what came before a group (per lane)

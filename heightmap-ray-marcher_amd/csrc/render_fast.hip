@@ -85,11 +85,6 @@ constexpr bool kAdaptive = kAdaptAfter > 0;
 #define HMRM_EARLY_LOAD 1
 #endif
 constexpr bool kEarlyLoad = HMRM_EARLY_LOAD != 0;
-// HMRM_MAX_LEGS: legs of one jump (see "CHAINED LEGS" in the attempt block).  1 = every binade's end costs a trip (round 4).
-#ifndef HMRM_MAX_LEGS
-#define HMRM_MAX_LEGS 1
-#endif
-constexpr int kMaxLegs = kStepsLeft ? HMRM_MAX_LEGS : 1;
 
 // ---- bilinear quality mode (HMRM_BILINEAR; a build-side addition, not in the reference) ----
 // Same definition, operation for operation, as oracle/hmrm_oracle.c "bilinear quality mode":
@@ -295,6 +290,10 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						// (a 32-bit byte offset from the pyramid's base: at most 8 planes of 2^27 floats, api.cpp's map limit)
 						float mf = *(const float *)((const char *)mip + (size_t)((inb0 ? widx : 0u) * 4u));
 						diag.load_end(f, 17, mf);
+						if (kEarlyLoad) refresh_stale();
+						const bool exact = kStepsLeft ? (ax.left | ay.left | az.left) >= 0
+						                              : ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
+						const int left_min = min(ax.left, min(ay.left, az.left)); // (kStepsLeft)
 						const int wx0 = ix << hs, wy0 = iy << hs;
 						// (the last windows of a row / column hang over the map's edge: the usable span ends at the edge)
 						const int wcells = top ? (1 << 30) : (4 << (kLevelStep * lev)); // window size S in cells
@@ -306,119 +305,81 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						// operand modifier -- and changes nothing for a moving coordinate.  No case distinction needed.)
 						const double ex = (double)(offx ? wx0 : wx0 + wspan_x) * gwid;  // x edge ahead
 						const double ey = -(double)(offy ? wy0 : wy0 + wspan_y) * gwid; // y edge ahead
-						// What the level policy below sees: the attempt's first leg, or the last successful one of a chained jump.
-						double room = 0.0, room_z = 0.0;
-						bool exact = false, above = false, z_bound = false, ok = false, can = false, binade_bound = false;
+						double room_lat = 0.0;
+						if (kStepsLeft) {
+							room_lat = __builtin_fmin(__builtin_fabs((ex - x) * ax.rdel), __builtin_fabs((ey - y) * ay.rdel));
+							// (computed here, not sunk behind the wait for the load: the empty statement reads the estimate
+							// and stands between the load and the first use of its result)
+							if (kEarlyLoad) asm volatile("" : "+v"(mf) : "v"(room_lat));
+						}
+						const double m = (double)mf; // (floats rounded up: also bounds every float / interpolated threshold)
+						const bool above = z >= m;
+						// Nothing below can succeed unless the ray is above this window's maximum: when no
+						// lane of the wave is, skip the estimate and the verification (the usual case in
+						// the last, nearly empty waves of a launch, which set its duration).
+						double room = 0.0, room_b = 0x1p40, room_z = 0.0;
+						bool z_bound = false, ok = false, can = false, binade_bound = false;
 						int n = 0;
-						// CHAINED LEGS (HMRM_MAX_LEGS > 1): a jump that a binade's end cut short goes on from its landing point inside the
-						// SAME window -- no new look-up, no trip through the level policy: the crossed coordinate is refreshed, the room is
-						// estimated again against the same edges and the same maximum, and the next landing point is verified like the
-						// first (inside the window, z >= maximum; the previous landing point was, so every position in between is too:
-						// monotonic coordinates).  A ray that enters the box near the origin crosses a dozen short binades of x or y on
-						// its first few hundred steps (profiles/r05_experiments.txt section 1); each cost its wave a whole trip.  One
-						// copy of the code: the loop's first pass is the attempt as it always was.
-						bool part = true; // this lane takes part in the pass
-						int legs = 0;     // (uniform)
-						do {
-							const bool first = legs == 0;
-							if (kEarlyLoad || !first) refresh_stale();
-							const bool exact_l = kStepsLeft ? (ax.left | ay.left | az.left) >= 0
-							                                : ax.key != 0xffffffffu && ay.key != 0xffffffffu && az.key != 0xffffffffu;
-							const int left_min = min(ax.left, min(ay.left, az.left)); // (kStepsLeft)
-							double room_lat = 0.0;
+						const bool cand = inb0 && exact && above;
+						if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
 							if (kStepsLeft) {
-								room_lat = __builtin_fmin(__builtin_fabs((ex - x) * ax.rdel), __builtin_fabs((ey - y) * ay.rdel));
-								// (computed here, not sunk behind the wait for the load: the empty statement reads the estimate
-								// and stands between the load and the first use of its result)
-								if (kEarlyLoad) asm volatile("" : "+v"(mf) : "v"(room_lat));
-							}
-							const double m = (double)mf; // (floats rounded up: also bounds every float / interpolated threshold)
-							const bool above_l = z >= m; // (later passes: true, the landing point was verified to be)
-							// Nothing below can succeed unless the ray is above this window's maximum: when no
-							// lane of the wave is, skip the estimate and the verification (the usual case in
-							// the last, nearly empty waves of a launch, which set its duration).
-							double room_l = 0.0, room_b = 0x1p40, room_z_l = 0.0;
-							bool z_bound_l = false, ok_l = false, can_l = false, binade_bound_l = false;
-							int n_l = 0;
-							const bool cand = part && inb0 && exact_l && above_l;
-							if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
-								if (kStepsLeft) {
-									room_l = room_lat;
-								} else {
-									room_l = (ax.lim - x) * ax.rdel;
-									room_l = __builtin_fmin(room_l, (ay.lim - y) * ay.rdel);
-									room_l = __builtin_fmin(room_l, (az.lim - z) * az.rdel);
-									room_b = room_l; // steps left inside the three binades
-									room_l = __builtin_fmin(room_l, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
-									room_l = __builtin_fmin(room_l, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
-								}
-								room_z_l = sz < 0.0 ? (m - z) * az.rdel : 0x1p40;
-								z_bound_l = room_z_l < room_l;
-								room_l = __builtin_fmin(room_l, room_z_l);
-								// (the saturating cast takes care of huge and negative estimates; the step budget caps the
-								// integer: a jump never takes more steps than the cap has left)
-								n_l = min(cvt_i32_sat(room_l * 0.998), budget) - 1;
-								if (kStepsLeft) { // (the binades' share is an exact count, not an estimate)
-									// (kCross: the jump's last step is a real one and may leave the binade)
-									const int left_lim = left_min + (kCross ? 1 : 0);
-									binade_bound_l = left_lim <= n_l;
-									z_bound_l = z_bound_l & !binade_bound_l;
-									n_l = min(n_l, left_lim);
-								} else {
-									binade_bound_l = room_b <= room_l;
-								}
-								can_l = cand && n_l >= kMinLeap;
-								// landing point and its exact verification
-								// (kCross: n - 1 steps by multiplication, all inside the three binades by count, then one real step
-								// from that exact position.  Coordinates move monotonically, so the tests of the end point below
-								// hold for every position before it.)
-								const double nn = (double)(kCross ? n_l - 1 : n_l);
-								const double xm = x + nn * ax.delta, ym = y + nn * ay.delta, zm = z + nn * az.delta;
-								const double xn = kCross ? xm + sx : xm, yn = kCross ? ym + sy : ym, zn = kCross ? zm + sz : zm;
-								bool nearn = false;
-								const double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
-								const int gxn = cvt_i32_sat(qxn), gyn = GWM == 0 ? cvt_i32_sat_neg(yn) : cvt_i32_sat(qyn);
-								const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim; // (diagnostics only)
-								// (inside the window implies inside the grid: the spans were cut at the map's edge)
-								// (kStepsLeft: n <= left of every axis, so the landing point is inside the three binades by count)
-								// (general grid widths, nearn: q' + 2^-20 lies in [k, k + 2^-19), so the landing cell is k = gxn or k - 1;
-								// both are asked to be inside the window, on both axes -- one flag serves the two)
-								const unsigned nm = (GWM == 2 && nearn) ? 1u : 0u;
-								ok_l = can_l && (unsigned)(gxn - wx0) - nm < (unsigned)wspan_x - nm &&
-								       (unsigned)(gyn - wy0) - nm < (unsigned)wspan_y - nm && zn >= m &&
-								       (kStepsLeft || (axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn)));
-								diag.on_landing_refused(f, can_l && !ok_l, inbn,
-								                        (unsigned)(gxn - wx0) < (unsigned)wspan_x && (unsigned)(gyn - wy0) < (unsigned)wspan_y, zn >= m);
-								x = ok_l ? xn : x;
-								y = ok_l ? yn : y;
-								z = ok_l ? zn : z;
-								budget -= ok_l ? n_l : 0;
-								if (kStepsLeft) {
-									const int took = ok_l ? n_l : 0;
-									ax.left -= took;
-									ay.left -= took;
-									az.left -= took;
-								}
-							}
-							if (kMaxLegs == 1) {
-								exact = exact_l; above = above_l; room = room_l; room_z = room_z_l;
-								z_bound = z_bound_l; binade_bound = binade_bound_l; can = can_l; ok = ok_l; n = n_l;
+								room = room_lat;
 							} else {
-								const bool keep = first | ok_l; // (a later pass that did not jump leaves the record of the one before)
-								exact = first ? exact_l : exact;
-								above = first ? above_l : above;
-								can = first ? can_l : can;
-								ok = first ? ok_l : ok;
-								room = keep ? room_l : room;
-								room_z = keep ? room_z_l : room_z;
-								z_bound = keep ? z_bound_l : z_bound;
-								binade_bound = keep ? binade_bound_l : binade_bound;
-								n = first ? n_l : n + (ok_l ? n_l : 0);
-								if (!first) diag.on_extra_leg(ok_l, n_l);
-								++legs;
-								part = ok_l && binade_bound_l && legs < kMaxLegs;
+								room = (ax.lim - x) * ax.rdel;
+								room = __builtin_fmin(room, (ay.lim - y) * ay.rdel);
+								room = __builtin_fmin(room, (az.lim - z) * az.rdel);
+								room_b = room; // steps left inside the three binades
+								room = __builtin_fmin(room, sx != 0.0 ? (ex - x) * ax.rdel : 0x1p40);
+								room = __builtin_fmin(room, sy != 0.0 ? (ey - y) * ay.rdel : 0x1p40);
 							}
-						} while (kMaxLegs > 1 && __builtin_amdgcn_ballot_w64(part) != 0ull);
+							room_z = sz < 0.0 ? (m - z) * az.rdel : 0x1p40;
+							z_bound = room_z < room;
+							room = __builtin_fmin(room, room_z);
+							// (the saturating cast takes care of huge and negative estimates; the step budget caps the
+							// integer: a jump never takes more steps than the cap has left)
+							n = min(cvt_i32_sat(room * 0.998), budget) - 1;
+							if (kStepsLeft) { // (the binades' share is an exact count, not an estimate)
+								// (kCross: the jump's last step is a real one and may leave the binade)
+								const int left_lim = left_min + (kCross ? 1 : 0);
+								binade_bound = left_lim <= n;
+								z_bound = z_bound & !binade_bound;
+								n = min(n, left_lim);
+							} else {
+								binade_bound = room_b <= room;
+							}
+							can = cand && n >= kMinLeap;
+							// landing point and its exact verification
+							// (kCross: n - 1 steps by multiplication, all inside the three binades by count, then one real step
+							// from that exact position.  Coordinates move monotonically, so the tests of the end point below
+							// hold for every position before it.)
+							const double nn = (double)(kCross ? n - 1 : n);
+							const double xm = x + nn * ax.delta, ym = y + nn * ay.delta, zm = z + nn * az.delta;
+							const double xn = kCross ? xm + sx : xm, yn = kCross ? ym + sy : ym, zn = kCross ? zm + sz : zm;
+							bool nearn = false;
+							const double qxn = cell_coord_fast<GWM>(xn, f, nearn), qyn = cell_coord_fast<GWM>(-yn, f, nearn);
+							const int gxn = cvt_i32_sat(qxn), gyn = GWM == 0 ? cvt_i32_sat_neg(yn) : cvt_i32_sat(qyn);
+							const bool inbn = (unsigned)gxn < wlim && (unsigned)gyn < hlim; // (diagnostics only)
+							// (inside the window implies inside the grid: the spans were cut at the map's edge)
+							// (kStepsLeft: n <= left of every axis, so the landing point is inside the three binades by count)
+							// (general grid widths, nearn: q' + 2^-20 lies in [k, k + 2^-19), so the landing cell is k = gxn or k - 1;
+							// both are asked to be inside the window, on both axes -- one flag serves the two)
+							const unsigned nm = (GWM == 2 && nearn) ? 1u : 0u;
+							ok = can && (unsigned)(gxn - wx0) - nm < (unsigned)wspan_x - nm &&
+							     (unsigned)(gyn - wy0) - nm < (unsigned)wspan_y - nm && zn >= m &&
+							     (kStepsLeft || (axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn)));
+							diag.on_landing_refused(f, can && !ok, inbn,
+							                        (unsigned)(gxn - wx0) < (unsigned)wspan_x && (unsigned)(gyn - wy0) < (unsigned)wspan_y, zn >= m);
+							x = ok ? xn : x;
+							y = ok ? yn : y;
+							z = ok ? zn : z;
+							budget -= ok ? n : 0;
+							if (kStepsLeft) {
+								const int took = ok ? n : 0;
+								ax.left -= took;
+								ay.left -= took;
+								az.left -= took;
+							}
+						}
 						diag.on_attempt_done(f, inb0, exact, above, n < kMinLeap, z_bound, can, ok, n, lev);
 						diag.on_bounds(ok, binade_bound);
 						// level policy (performance only; any policy gives the same pixels):
