@@ -33,10 +33,14 @@ N = 1: `value` / `ms_per_step` = K frames of the workload's static pose launched
          workloads         the other BASELINE configurations on this GPU, each with kernel_ms (HIP
                            events), ms_per_step (host clock, one stream), Mrays/s, reference-equivalent
                            and executed steps: C3h (the north_star target: step_dist 0.5), C5 (static
-                           pose), C2, C4 (7680x4320 over 8192^2, the whole frame on one GPU);
+                           pose), C2, C4 (7680x4320 over 8192^2, the whole frame on one GPU), and the reference's
+                           own operating points: C3/gw0.05 (its default grid_width) and REFDEF (its sample config);
+         operating_range   best / moving camera / reference defaults / worst content, ms per frame at a glance;
          literal_kernel    HMRM_KERNEL=simple on the headline frame: the kernel that executes every
                            one of the reference's loads, with SURVEY 8(d)'s algorithmic-bytes fraction
                            of the HBM peak (the figure that formula is defined for);
+         every_load_kernel HMRM_KERNEL=group on the headline frame: the fastest kernel that still executes
+                           every one of those loads (speculative groups, no leaps), same byte roofline;
          rough_terrain     the headline camera over maps built to defeat the traversal (white noise,
                            a 255-spike per 256^2 block, needles on a plateau, a canyon flown at low
                            altitude): the library as shipped against the plain 4-step groups.
@@ -352,6 +356,25 @@ def dry_main(args, job):
     ok = True
     if rank == 0:
         ok = bool(np.array_equal(out["frame"].numpy(), pattern_rows(range(H))))
+    # the pipelined sequence (double-buffered strips, chunked gathers, rotating root) with the same pattern
+    pipe = strips.StripPipeline(plan, rank, job.dist if world > 1 else None, torch, "cpu", depth=2, chunks=2, rotate_root=True)
+
+    def render_chunk_of(k):
+        def render_chunk(chunk_t, band_rows, band_index, band_count):
+            vplan = strips.BandPlan(height=H, width=W, band_rows=band_rows, world=band_count)
+            host = chunk_t.numpy()
+            host[:] = 0
+            for j, b in enumerate(vplan.bands_of(band_index)):
+                g0, g1 = b * band_rows, min((b + 1) * band_rows, H)
+                host[j * band_rows:j * band_rows + (g1 - g0)] = pattern_rows(range(g0, g1), k)
+        return render_chunk
+    piped = {}
+    pipe.run(range(5), render_chunk_of, on_frame=lambda k, f: piped.__setitem__(k, f))
+    for k in range(5):
+        if rank == k % world:
+            ok = ok and piped[k] is not None and bool(np.array_equal(piped[k].numpy(), pattern_rows(range(H), k)))
+        else:
+            ok = ok and piped[k] is None
     bad = job.total(0 if ok else 1)
     if rank == 0:
         if bad:
@@ -549,18 +572,76 @@ def main(argv=None):
 
             def step_own():
                 strips.render_strip_to_host(plan, the_rank, render_rows4, strip, host_strip)
+            # the pipelined sequence (strips.StripPipeline): two strip buffers per rank, the gather on its own stream, frames
+            # rendered and gathered in 4 interleaved band sets; to rank 0, and with the root rotating (frame k on GPU k mod N)
+            pipes = {}
+
+            def make_pipe(rotate):
+                if not active:
+                    return None
+                use_dist = job.dist if plan.world > 1 else None
+                if use_dist is not None and job.share_gpu:  # (rehearsal: gloo gathers host tensors)
+                    return strips.StripPipeline(plan, the_rank, use_dist, torch, "cpu", depth=2, chunks=4, rotate_root=rotate)
+                return strips.StripPipeline(plan, the_rank, use_dist, torch, "cuda", depth=2, chunks=4, rotate_root=rotate,
+                                            render_stream=torch.cuda.current_stream() if use_dist is not None else None,
+                                            comm_stream=torch.cuda.Stream() if use_dist is not None else None)
+
+            def render_chunk(chunk_t, band_rows, band_index, band_count):
+                if chunk_t.is_cuda:
+                    render_rows4(chunk_t, band_rows, band_index, band_count)
+                else:  # (share-gpu rehearsal: render on the GPU that is there, hand the gather a host copy)
+                    tmp = torch.empty(chunk_t.shape, dtype=torch.uint8, device="cuda")
+                    render_rows4(tmp, band_rows, band_index, band_count)
+                    chunk_t.copy_(tmp)
+
+            def pipe_step(tag):
+                st_ = pipes[tag]
+
+                def step():
+                    pipe, pending = st_["pipe"], st_["pending"]
+                    if len(pending) == pipe.depth:
+                        j = pending.pop(0)
+                        f = pipe.collect(j)
+                        if f is not None:
+                            st_["last"] = f
+                    pipe.submit(st_["k"], render_chunk)
+                    pending.append(st_["k"])
+                    st_["k"] += 1
+                return step
+
+            def pipe_drain(tag):
+                st_ = pipes[tag]
+                for j in st_["pending"]:
+                    f = st_["pipe"].collect(j)
+                    if f is not None:
+                        st_["last"] = f
+                st_["pending"] = []
+            for tag, rotate in (("pipelined_to_rank0", False), ("pipelined_rotating_root", True)):
+                pipes[tag] = {"pipe": make_pipe(rotate), "pending": [], "k": 0, "last": None}
             legs = {}
-            for name, fn in (("kernel_only", step_kernel), ("gather_to_rank0_over_rccl", step_gather), ("own_pcie_link_no_collective", step_own)):
+            for name, fn in (("kernel_only", step_kernel), ("gather_to_rank0_over_rccl", step_gather), ("own_pcie_link_no_collective", step_own),
+                             ("pipelined_to_rank0", pipe_step("pipelined_to_rank0")), ("pipelined_rotating_root", pipe_step("pipelined_rotating_root"))):
                 if active:
                     for _ in range(3):
                         fn()
                 dt4 = timed(fn if active else (lambda: None), n_frames)
+                if active and name in pipes:
+                    pipe_drain(name)
                 legs[name] = {"ms_per_frame": dt4 * 1e3 / n_frames, "value": steps4 * n_frames / dt4}
+            for tag in pipes:
+                legs[tag]["note"] = ("strips.StripPipeline: 2 frames in flight (double-buffered strips, gather on its own stream), 4 interleaved band "
+                                     "sets per frame; throughput of a SEQUENCE of frames, each still rendered by all ranks" +
+                                     ("; frame k is gathered to rank k mod N" if tag.endswith("root") else ""))
             ok = True
             if active:
                 ok = strips.strip_rows_match(plan, the_rank, host_strip.numpy(), fb4)
                 if the_rank == 0:
                     ok = ok and np.array_equal(result["frame4"].cpu().numpy(), fb4)
+                for tag in pipes:  # (every rank that was a root of some frame checks the last one it received)
+                    if pipes[tag]["last"] is not None:
+                        ok = ok and np.array_equal(pipes[tag]["last"].cpu().numpy(), fb4)
+                    elif the_rank == 0:
+                        ok = False
             if total_over_ranks(0 if ok else 1):
                 raise SystemExit("bench.py: a c4_strips leg produced different pixels than hmrm_render_stats")
             return legs
@@ -578,7 +659,8 @@ def main(argv=None):
         return block
 
     def executed(st_):
-        return {"height_samples": int(st_.groups) * 4 if st_.groups else None, "pyramid_lookups": int(st_.leap_attempts),
+        # (positions per speculative group: 4 in the production kernel, 6 in the plain-groups kernel -- render_fast.hip kGroup / kGroupPlain)
+        return {"height_samples": int(st_.groups) * (4 if st_.leap_attempts else 6) if st_.groups else None, "pyramid_lookups": int(st_.leap_attempts),
                 "steps_covered_by_exact_leaps": int(st_.leaped_steps)}
 
     def workload_block(w, the_scene, n_frames, n_warm):
@@ -740,6 +822,27 @@ def main(argv=None):
                              "traffic_over_algorithmic": (lit_traffic / algo_bytes) if lit_traffic else None, "pmc": lit_prov}}
         guarded("literal_kernel", blk_literal)
 
+        # ---- ... and the fastest kernel of the library that still executes every one of those loads: the speculative groups
+        # without leaps (what a scene renders with when its content admits no jumps).  Same byte roofline.
+        def blk_every_load():
+            def group():
+                scene.bench_kernel_ms(cam, 3)
+                return scene.bench_kernel_ms(cam, 10)
+            grp_ms = with_kernel("group", group)
+            grp_pmc, grp_prov = _pmc_from_profiles(wl.name + "_group", hmrm.kernel_src_sha())
+            grp_traffic = grp_pmc.get("hbm_bytes_per_launch") if grp_pmc else None
+            secondary["every_load_kernel"] = {
+                "kernel": "k_render_fast<.., LEAP = false> (HMRM_KERNEL=group): groups of 6 speculative positions, their height loads issued "
+                          "together, tests resolved in order; every load of main/hmap.cpp:1013 is executed, none is proved away",
+                "launches": 10, "kernel_ms": grp_ms, "value": frame_steps / (grp_ms * 1e-3), "unit": "ray-steps/s (executed, not equivalent)",
+                "production_speedup": grp_ms / kernel_ms,
+                "roofline": {"bound": "hbm", "achieved": algo_bytes / (grp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": algo_bytes / (grp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
+                             "traffic": grp_traffic,
+                             "traffic_over_algorithmic": (grp_traffic / algo_bytes) if grp_traffic else None,
+                             "wave_time": (grp_pmc or {}).get("wave_time"), "pmc": grp_prov}}
+        guarded("every_load_kernel", blk_every_load)
+
         # ---- the other BASELINE configurations on this GPU
         n_w = max(5, min(args.steps, 50))
         blocks = {}
@@ -753,6 +856,13 @@ def main(argv=None):
                 scene2 = hmrm.Scene(*maps_of(w2), w2.scene_params())
                 blocks["C2"] = workload_block(w2, scene2, n_w, 5)
                 scene2.close()
+                # the reference's own operating points: its default grid_width 0.05 (main/hmap.cpp:65) under the headline's
+                # camera and cells, and its sample config's grid_width 0.01 with step_dist 0.05 = 5 cells per step
+                # (sample_config.txt:5-7) on the C5 frame.  Same maps; the scene parameters differ (grid width, heights).
+                for wr in (synth.grid_workload("C3", 0.05), synth.WORKLOADS["REFDEF"]):
+                    scene_r = hmrm.Scene(rgb, cmap, wr.scene_params())
+                    blocks[wr.name] = workload_block(wr, scene_r, n_w, 5)
+                    scene_r.close()
         guarded("workloads", blk_workloads)
 
         # ---- maps built to defeat the traversal: the library as shipped against the plain 4-step groups
@@ -902,6 +1012,22 @@ def main(argv=None):
         if job.rccl_ranks is not None:
             line["rccl_ranks"] = job.rccl_ranks
         line.update(secondary)
+        if world == 1 and secondary.get("workloads"):
+            # the span of operating points at a glance (every figure is also in its own block above): ms per frame on one
+            # stream (kernel_ms where the block has one), 3840x2160 over the 4096^2 map throughout
+            wk = secondary["workloads"]
+            rough = {k: v for k, v in (secondary.get("rough_terrain") or {}).items() if isinstance(v, dict)}
+            worst = max(rough.items(), key=lambda kv: kv[1]["kernel_ms"]) if rough else None
+            fc = secondary.get("fresh_camera") or {}
+            line["operating_range"] = {
+                "best": {"what": "static pose, calibrated launch order, grid_width 1 (the headline)", "ms_per_step": ms_per_step, "kernel_ms": kernel_ms},
+                "moving": {"what": "a camera the library has never seen, every frame (host set-up in the loop)", "ms_per_step": fc.get("ms_per_step")},
+                "reference_defaults": {name: {"what": workload_text(synth.grid_workload("C3", 0.05) if name != "REFDEF" else synth.WORKLOADS["REFDEF"]),
+                                              "ms_per_step": wk[name]["ms_per_step"], "kernel_ms": wk[name]["kernel_ms"]}
+                                       for name in ("C3/gw0.05", "REFDEF") if name in wk},
+                "worst_content": ({"what": "the headline camera over `" + worst[0] + "` (rough_terrain)", "kernel_ms": worst[1]["kernel_ms"],
+                                   "kernel": worst[1]["kernel_chosen_by_probe"]} if worst else None),
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hmrm, wl, rgb, cmap, params, cam, args.cpu_seconds)
         sys.stdout.flush()

@@ -62,6 +62,7 @@ struct Knobs {
 	int finest_pause = -1;               // HMRM_FINEST_PAUSE (tools)
 	bool order_verbose = false;          // HMRM_ORDER_VERBOSE=1 (tools): report every calibration on stderr
 	bool try_group = true;               // HMRM_TRY_GROUP=0: the calibration does not time the plain-groups kernel against the leap kernel
+	int min_plane_shift = 0;             // HMRM_DEBUG_PLANE_SHIFT (tests): log2 of the pyramid's plane pitch is at least this
 	int seg_n = 0;                       // HMRM_TILE_SEGMENTS=b0:c0,b1:c1,.. (tools): tile-row pieces to start first, in this order
 	int seg_b[3] = {0, 0, 0}, seg_c[3] = {0, 0, 0};
 };
@@ -93,6 +94,10 @@ Knobs read_knobs() {
 			if (*s != ',') break;
 			++s;
 		}
+	}
+	if (const char *s = getenv("HMRM_DEBUG_PLANE_SHIFT")) {
+		const int v = atoi(s);
+		if (v > 0 && v <= 28) k.min_plane_shift = v; // (8 planes of 2^28 floats: 8 GiB, the layout of the largest legal map)
 	}
 	if (const char *s = getenv("HMRM_MIN_LEVEL"))
 		if (s[0] >= '0' && s[0] < '0' + hmrm::kMipLevels) k.min_level = s[0] - '0';
@@ -215,7 +220,6 @@ struct hmrm_scene {
 	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/8/../256-cell windows every 2/4/../128 cells
 	int32_t mip_w[hmrm::kMipLevels] = {}, mip_h[hmrm::kMipLevels] = {};
 	int32_t mip_row = 0, mip_plane_shift = 0; // plane layout of both pyramids, see DevFrame
-	bool mip_offsets_fit = true; // every look-up's byte offset fits 32 bits (hmrm_scene_create); else the literal loop renders
 	size_t mip_floats() const { return (size_t)(hmrm::kMipLevels + 1) << mip_plane_shift; }
 	float *plane(float *buf, int l) const { return buf + ((size_t)l << mip_plane_shift); }
 	hipStream_t stream = nullptr; // the scene's own stream (hmrm_render, updates)
@@ -546,7 +550,7 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 		// calibration (see plan_order_from_measurement): full frames of the production kernel only
 		const bool eligible = !pieces && !stats && s->knobs.tile_order && s->knobs.order_mode == 2 && s->knobs.kernel != 2 &&
 		                      rows.band_rows == 0 && rows.row_begin == 0 && rows.local_rows == f.screen_h && tiles_y >= 12 &&
-		                      tiles_y <= kMaxMeasRows && s->map_w < (1 << 24) && s->map_h < (1 << 24) && s->mip_offsets_fit;
+		                      tiles_y <= kMaxMeasRows && s->map_w < (1 << 24) && s->map_h < (1 << 24);
 		if (eligible) {
 			++slot->uses;
 			const size_t idx = (size_t)(slot - c->slots);
@@ -684,10 +688,9 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 	}
 	// the production kernel indexes cells and windows with 24-bit multiplies (leap_common.hpp index_2d): a map
 	// with a side of 2^24 cells or more (then at most 32 cells the other way) goes through the literal loop
-	// ... and so does one whose pyramid planes are too far apart for the look-up's 32-bit byte offsets (hmrm_scene_create)
-	const bool huge_side = s->map_w >= (1 << 24) || s->map_h >= (1 << 24) || !s->mip_offsets_fit;
+	const bool huge_side = s->map_w >= (1 << 24) || s->map_h >= (1 << 24);
 	if (huge_side && f.sampling != 0)
-		return fail(HMRM_E_ARG, "maps with a side of 2^24 cells or more, or more than 2^27 level-0 pyramid windows, support nearest sampling only");
+		return fail(HMRM_E_ARG, "maps with a side of 2^24 cells or more support nearest sampling only");
 	if ((s->knobs.kernel == 2 || huge_side) && f.sampling == 0) { // (the literal loop only knows the reference's sampling)
 		HIP_TRY(hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters, d_steps,
 		                            d_entry, stats, c->stream));
@@ -709,19 +712,19 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 }
 
 // Pyramid layout of a map (DevFrame): windows per level, the common row pitch (level 0's) and the log2 of the
-// power-of-two plane pitch.  Returns whether every look-up's byte offset fits 32 bits: k_render_fast forms
-// ((lev << shift) + index) * 4 in 32 bits, so (kMipLevels + 1) << shift must not exceed 2^30 floats.  Every
-// square-ish map up to hmrm_scene_create's 2^29-cell limit fits (shift <= 27); a very oblong one (16385 x 32766:
-// level 0 has 8193 x 16383 windows, shift 28) does not and is rendered by the literal loop (launch_frame), like
-// maps with a side of 2^24 cells.
-bool mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_w, int32_t *mip_h, int32_t *mip_row, int32_t *plane_shift) {
+// power-of-two plane pitch (at least min_shift: tests force far-apart planes on small maps).  The kernel forms the
+// ELEMENT index (lev << shift) + index in 32 bits -- (kMipLevels + 1) << shift never exceeds 2^31 for a map within
+// hmrm_scene_create's 2^29-cell limit -- and the byte offset in 64.  Returns whether 32-bit BYTE offsets would have been
+// enough (informational since round 5: every square-ish map; not 16385 x 32766, whose level 0 has 8193 x 16383 windows,
+// shift 28 -- round 4 rendered such maps with the literal loop).
+bool mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_w, int32_t *mip_h, int32_t *mip_row, int32_t *plane_shift, int32_t min_shift = 0) {
 	for (int l = 0; l < hmrm::kMipLevels; ++l) {
 		const int stride = 1 << hmrm::mip_stride_shift(l); // windows of win_cells(l) cells every stride cells
 		mip_w[l] = (map_w + stride - 1) / stride;
 		mip_h[l] = (map_h + stride - 1) / stride;
 	}
 	*mip_row = mip_w[0];
-	*plane_shift = 0;
+	*plane_shift = min_shift;
 	while (((size_t)1 << *plane_shift) < (size_t)hmrm::mip_index(mip_w[0] - 1, mip_h[0] - 1, *mip_row) + 1) ++*plane_shift;
 	return ((uint64_t)(hmrm::kMipLevels + 1) << *plane_shift) <= ((uint64_t)1 << 30);
 }
@@ -898,7 +901,7 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 		HIP_TRY(hipMalloc((void **)&s->d_thr, n * sizeof(double)));
 		// every plane has level 0's row pitch and a power-of-two plane pitch (DevFrame); the pyramid of the
 		// bilinear mode is allocated by its first frame
-		s->mip_offsets_fit = mip_layout(map_w, map_h, s->mip_w, s->mip_h, &s->mip_row, &s->mip_plane_shift);
+		(void)mip_layout(map_w, map_h, s->mip_w, s->mip_h, &s->mip_row, &s->mip_plane_shift, s->knobs.min_plane_shift);
 		HIP_TRY(hipMalloc((void **)&s->d_mipbuf, s->mip_floats() * sizeof(float)));
 		HIP_TRY(hipMalloc((void **)&s->d_maxkey, sizeof(unsigned long long)));
 		HIP_TRY(hipMemcpyAsync(s->d_rgb, height_rgb, n * 3, hipMemcpyHostToDevice, s->stream));
@@ -1778,8 +1781,8 @@ int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params, in
 	return HMRM_OK;
 }
 
-// Test hook (no GPU): the pyramid layout hmrm_scene_create would choose for a map, and whether the production
-// kernel's 32-bit look-up offsets cover it (0: the scene is rendered by the literal loop).
+// Test hook (no GPU): the pyramid layout hmrm_scene_create would choose for a map, and whether 32-bit BYTE offsets
+// would cover it (0: only the kernel's 64-bit offsets do -- informational since round 5).
 int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_t *plane_shift, int32_t *levels) {
 	if (map_w <= 0 || map_h <= 0 || (int64_t)map_w * map_h > ((int64_t)1 << 31) / 4) return fail(HMRM_E_ARG, "bad map dimensions");
 	int32_t w[hmrm::kMipLevels], h[hmrm::kMipLevels], row = 0, shift = 0;

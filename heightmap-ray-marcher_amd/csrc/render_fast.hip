@@ -58,7 +58,16 @@ namespace {
 #ifndef HMRM_GROUP
 #define HMRM_GROUP 4
 #endif
-constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group
+constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group of the production kernel
+// ... and of the plain-groups instantiation (LEAP = false: no leaps, every height load of the reference is executed --
+// what the scene's probe picks on content that admits no jumps, and the kernel SURVEY 8(d)'s byte roofline is defined
+// for).  That kernel waits for its gathers 70 % of the time at 17 % VALU busy (profiles/r05_C3_group_rocprof.txt): more
+// loads in flight per lane pay until the registers cost resident waves -- C3 2.61 ms with 4, 2.37 with 6, 2.57 with 8
+// (profiles/r05_raw/group_len_ab.txt).
+#ifndef HMRM_GROUP_PLAIN
+#define HMRM_GROUP_PLAIN 6
+#endif
+constexpr int kGroupPlain = HMRM_GROUP_PLAIN;
 #ifndef HMRM_MIN_LEAP
 #define HMRM_MIN_LEAP 2
 #endif
@@ -163,6 +172,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
                                                 int64_t out_stride_px, int tiles_y, const StatsOut &st, int tile_x, unsigned gy,
                                                 int wave, int lane) {
 	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
+	constexpr int U = LEAP ? kGroup : kGroupPlain; // positions per speculative group
 	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
 	const float *__restrict__ mip = BILINEAR ? f.mipbuf_bil : f.mipbuf; // the pyramid this sampling mode leaps on
 	const PixelId pid = pixel_of_tile_lane(f, rows, tiles_y, tile_x, gy, wave, lane);
@@ -287,8 +297,15 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						iy = iy < 0 ? 0 : iy;
 						const unsigned widx = ((unsigned)lev << f.mip_plane_shift) + (unsigned)index_2d(iy, f.mip_row, ix); // (= mip_index)
 						diag.load_begin(f, 17);
-						// (a 32-bit byte offset from the pyramid's base: at most 8 planes of 2^27 floats, api.cpp's map limit)
-						float mf = *(const float *)((const char *)mip + (size_t)((inb0 ? widx : 0u) * 4u));
+#ifndef HMRM_WIDE_MIP
+#define HMRM_WIDE_MIP 1
+#endif
+						// (the element index fits 32 bits -- 8 planes of at most 2^28 floats, api.cpp's map limit -- the byte offset
+						// need not: a 64-bit offset, one v_lshl_add_u64 where the 32-bit form had a shift.  Measured equal within the
+						// run-to-run spread on C3 / C5 / C2 / C4, profiles/r05_raw/wide_mip_abn.txt; with HMRM_WIDE_MIP 0 -- round 4 --
+						// very oblong maps near the 2^29-cell limit, 16385 x 32766, had to be rendered by the literal loop, 85 x slower.)
+						float mf = HMRM_WIDE_MIP ? mip[(size_t)(inb0 ? widx : 0u)]
+						                         : *(const float *)((const char *)mip + (size_t)((inb0 ? widx : 0u) * 4u));
 						diag.load_end(f, 17, mf);
 						if (kEarlyLoad) refresh_stale();
 						const bool exact = kStepsLeft ? (ax.left | ay.left | az.left) >= 0
@@ -430,24 +447,24 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 
 				// --------------------------------------------- speculative group
 				diag.on_group();
-				double X[kGroup], Y[kGroup], Z[kGroup], T[kGroup];
-				unsigned cell[kGroup]; // (unsigned: the 64-bit address needs no sign extension)
-				bool inb[kGroup];
+				double X[U], Y[U], Z[U], T[U];
+				unsigned cell[U]; // (unsigned: the 64-bit address needs no sign extension)
+				bool inb[U];
 				X[0] = x; Y[0] = y; Z[0] = z;
 #pragma unroll
-				for (int j = 1; j < kGroup; ++j) {
+				for (int j = 1; j < U; ++j) {
 					X[j] = X[j - 1] + sx;
 					Y[j] = Y[j - 1] + sy;
 					Z[j] = Z[j - 1] + sz;
 				}
-				// cells of the kGroup positions.  Only the integers are kept: the general-grid-width quotient q' is needed for
+				// cells of the U positions.  Only the integers are kept: the general-grid-width quotient q' is needed for
 				// nothing but its truncation (and the test whether it is too close to an integer to be trusted), and holding
-				// kGroup pairs of them cost the general instantiations 12 vector registers (76: 6 waves per SIMD).  The
+				// U pairs of them cost the general instantiations 12 vector registers (76: 6 waves per SIMD).  The
 				// bilinear mode needs the exact quotients themselves (its weights) and keeps them.
-				double QX[BILINEAR ? kGroup : 1], QY[BILINEAR ? kGroup : 1];
+				double QX[BILINEAR ? U : 1], QY[BILINEAR ? U : 1];
 				bool near = false;
 #pragma unroll
-				for (int j = 0; j < kGroup; ++j) {
+				for (int j = 0; j < U; ++j) {
 					int gx, gy;
 					if constexpr (BILINEAR && GWM != 0) { // (the exact q: true division unless the reciprocal is exact)
 						QX[j] = GWM == 2 ? X[j] / f.grid_width : X[j] * f.inv_grid_width;
@@ -465,7 +482,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 				}
 				if (GWM == 2 && !BILINEAR && near) { // some position is on a cell boundary to within 2^-20: divide for real
 #pragma unroll
-					for (int j = 0; j < kGroup; ++j) {
+					for (int j = 0; j < U; ++j) {
 						// (one division at a time: interleaved, their temporaries set the kernel's register count)
 						__builtin_amdgcn_sched_barrier(0);
 						const int gx = cvt_i32_sat(X[j] / f.grid_width);
@@ -479,7 +496,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 				diag.load_begin(f, 18);
 				if constexpr (BILINEAR) {
 #pragma unroll
-					for (int j = 0; j < kGroup; ++j) {
+					for (int j = 0; j < U; ++j) {
 						const Bil b = bil_setup(inb[j] ? QX[j] : 0.0, inb[j] ? QY[j] : 0.0, f.map_w, f.map_h);
 						T[j] = bil_mix(b, thr[b.c00], thr[b.c10], thr[b.c01], thr[b.c11]);
 					}
@@ -487,18 +504,18 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 #pragma unroll
 					// (32-bit byte offsets from the table's base -- api.cpp caps maps at 2^29 cells -- so that the loads can
 					// take the base from scalar registers: no 64-bit address arithmetic per sample)
-					for (int j = 0; j < kGroup; ++j)
+					for (int j = 0; j < U; ++j)
 						T[j] = F32 ? (double)*(const float *)((const char *)thr32 + (size_t)(cell[j] * 4u))
 						           : *(const double *)((const char *)thr + (size_t)(cell[j] * 8u)); // hmap.cpp:1013-1014 (+ c0.z)
 				}
-				if (kGroup == 4) diag.load_end(f, 18, T[0], T[1], T[2], T[3]);
-				if (budget >= kGroup) {
+				if constexpr (U == 4) diag.load_end(f, 18, T[0], T[1], T[2], T[3]);
+				if (budget >= U) {
 					// in order: the first position that leaves the grid (:1006) or hits (:1016) ends the ray
-					int first = kGroup, hit_j = 0;
+					int first = U, hit_j = 0;
 					unsigned hit_cell = 0u;
 					bool hit = false;
 #pragma unroll
-					for (int j = kGroup - 1; j >= 0; --j) { // (selects, last write = earliest position)
+					for (int j = U - 1; j >= 0; --j) { // (selects, last write = earliest position)
 						const bool h = inb[j] && Z[j] < T[j];
 						const bool s = !inb[j] || h;
 						first = s ? j : first;
@@ -508,14 +525,14 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 					}
 					const int taken = first + (hit ? 1 : 0); // loads the reference executed in this group
 					budget -= taken;
-					done = first < kGroup;
+					done = first < U;
 					if (hit) {
 						if constexpr (BILINEAR) {
 							// (the weights are rebuilt for the one position that hit: cheaper than keeping
-							// kGroup sets of them alive)
+							// U sets of them alive)
 							double qxh = QX[0], qyh = QY[0];
 #pragma unroll
-							for (int j = 1; j < kGroup; ++j) {
+							for (int j = 1; j < U; ++j) {
 								qxh = hit_j == j ? QX[j] : qxh;
 								qyh = hit_j == j ? QY[j] : qyh;
 							}
@@ -531,7 +548,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 					// indexed dynamically
 					double xs = x, ys = y, zs = z;
 #pragma unroll 1
-					for (int j = 0; j < kGroup; ++j) {
+					for (int j = 0; j < U; ++j) {
 						const double qx = (GWM == 0) ? xs : xs / f.grid_width, qy = (GWM == 0) ? -ys : -ys / f.grid_width;
 						const int gx = cvt_i32_sat(qx), gy = cvt_i32_sat(qy);
 						if (!((unsigned)gx < wlim && (unsigned)gy < hlim)) { done = true; break; }
@@ -557,13 +574,13 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						zs += sz;
 					}
 				}
-				x = X[kGroup - 1] + sx;
-				y = Y[kGroup - 1] + sy;
-				z = Z[kGroup - 1] + sz;
-				if (LEAP && kStepsLeft) { // kGroup real steps further inside (or out of) the binades
-					ax.left -= kGroup;
-					ay.left -= kGroup;
-					az.left -= kGroup;
+				x = X[U - 1] + sx;
+				y = Y[U - 1] + sy;
+				z = Z[U - 1] + sz;
+				if (LEAP && kStepsLeft) { // U real steps further inside (or out of) the binades
+					ax.left -= U;
+					ay.left -= U;
+					az.left -= U;
 				}
 			}
 			if (STATS) my_steps = (unsigned long long)(unsigned)(budget0 - budget);

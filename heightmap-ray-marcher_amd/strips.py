@@ -118,3 +118,116 @@ def strip_rows_match(plan: BandPlan, rank: int, host_strip, frame) -> bool:
         if not np.array_equal(hs[k * plan.band_rows:k * plan.band_rows + (g1 - g0)], fr[g0:g1]):
             return False
     return True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A SEQUENCE of frames over the ranks, pipelined.  render_frame_distributed is render -> gather ->
+# return: the gather of 7/8 of a frame into one GPU is longer than the kernel of an eighth of it (C4: 7 strips of 16.6 MB
+# against ~0.07 ms of kernel), and nothing overlaps.  Here
+#   * frame k + 1 renders while frame k's strips are on the wire: `depth` strip buffers per rank, the gather on its own
+#     stream behind an event of the render stream, a buffer reused only when its gather is done;
+#   * a frame is rendered and gathered in `chunks` interleaved band sets (chunk c of rank r = the bands of the virtual
+#     rank r + world * c among world * chunks), so that the root starts receiving when the first chunk is rendered, not the
+#     last;
+#   * `rotate_root`: frame k is gathered to rank k mod world.  Into ONE GPU a C4 frame needs 116 MB / (7 links in) per
+#     frame whatever is overlapped; with the root rotating every link carries one strip per direction per `world` frames
+#     and the sequence is bound by the kernels (DESIGN.md section 7 has the arithmetic).  Each frame still exists whole on
+#     one GPU -- its root -- which is where a consumer of a frame sequence (an encoder per GPU, each GPU's own PCIe link)
+#     wants it.
+# The code is the same for RCCL on GPUs (streams and events given) and for gloo in the CPU tests (streams None: the
+# asynchronous gather's work handle alone orders things).
+class StripPipeline:
+    def __init__(self, plan: BandPlan, rank: int, dist, torch, device, depth: int = 2, chunks: int = 1,
+                 rotate_root: bool = False, render_stream=None, comm_stream=None):
+        assert depth >= 1 and chunks >= 1
+        self.plan, self.rank, self.dist, self.torch = plan, rank, dist, torch
+        self.depth, self.chunks, self.rotate_root = depth, chunks, rotate_root
+        self.render_stream, self.comm_stream = render_stream, comm_stream
+        # chunk c of this rank = virtual rank (rank + world * c) of a plan over world * chunks virtual ranks
+        self.vplan = BandPlan(height=plan.height, width=plan.width, band_rows=plan.band_rows, world=plan.world * chunks)
+        rows = self.vplan.strip_rows
+        self.strips = [torch.zeros((chunks, rows, plan.width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
+        # (every rank may be a root when the root rotates)
+        self.blocks = [torch.zeros((self.vplan.world, rows, plan.width, 4), dtype=torch.uint8, device=device)
+                       if (rotate_root or rank == 0) else None for _ in range(depth)]
+        self.inflight = [None] * depth  # per slot: (frame index, root, [work handles], event or None)
+        self.log = []                   # (what, frame, chunk): the order things were issued in (tests)
+
+    def root_of(self, k: int) -> int:
+        return k % self.plan.world if self.rotate_root else 0
+
+    def _drain_slot(self, slot):
+        fl = self.inflight[slot]
+        if fl is None:
+            return None
+        k, root, works, ev = fl
+        for w in works:
+            w.wait()  # (RCCL: makes the current stream wait; gloo: blocks until the bytes are there)
+        if ev is not None:
+            ev.synchronize()
+        self.inflight[slot] = None
+        self.log.append(("drained", k, -1))
+        return k, root
+
+    def submit(self, k: int, render_rows):
+        """Start frame k: render_rows(strip_chunk, band_rows, band_index, band_count) per chunk, each chunk's gather behind
+        it.  Returns at once (asynchronous on GPUs); the frame is collected with `collect(k)`."""
+        torch = self.torch
+        slot = k % self.depth
+        # the slot's buffers are free once frame k - depth has been collected: its gather has finished (strips) and its
+        # frame has been copied out of the block (reassembly)
+        assert self.inflight[slot] is None, "submit(k): frame k - depth has not been collected yet"
+        root = self.root_of(k)
+        world, works = self.plan.world, []
+        for c in range(self.chunks):
+            chunk = self.strips[slot][c]
+            render_rows(chunk, self.plan.band_rows, self.rank + world * c, self.vplan.world)
+            self.log.append(("rendered", k, c))
+            dst = list(self.blocks[slot][c * world:(c + 1) * world].unbind(0)) if self.rank == root else None
+            if self.comm_stream is not None:
+                ready = torch.cuda.Event()
+                ready.record(self.render_stream)
+                self.comm_stream.wait_event(ready)
+                with torch.cuda.stream(self.comm_stream):
+                    works.append(self.dist.gather(chunk, gather_list=dst, dst=root, async_op=True))
+            elif self.dist is not None and world > 1:
+                works.append(self.dist.gather(chunk, gather_list=dst, dst=root, async_op=True))
+            elif dst is not None:
+                dst[0].copy_(chunk)
+            self.log.append(("gather issued", k, c))
+        ev = None
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(self.comm_stream):
+                for w in works:
+                    w.wait()
+                ev.record(self.comm_stream)
+            works = []
+        self.inflight[slot] = (k, root, works, ev)
+
+    def collect(self, k: int):
+        """Wait for frame k.  On its root: the reassembled (height, width, 4) frame; elsewhere None."""
+        slot = k % self.depth
+        fl = self.inflight[slot]
+        assert fl is not None and fl[0] == k, "collect(k): frame k is not in flight (collected already, or overwritten by frame k + depth)"
+        _, root = self._drain_slot(slot)
+        if self.rank != root:
+            return None
+        return reassemble_torch(self.vplan, self.blocks[slot])
+
+    def run(self, frames, render_rows_of, on_frame=None):
+        """frames: iterable of frame indices; render_rows_of(k) -> the render_rows callable of frame k.  Keeps `depth`
+        frames in flight; on_frame(k, frame_or_None) is called for every frame in order."""
+        pending = []
+        for k in frames:
+            if len(pending) == self.depth:
+                j = pending.pop(0)
+                f = self.collect(j)
+                if on_frame:
+                    on_frame(j, f)
+            self.submit(k, render_rows_of(k))
+            pending.append(k)
+        for j in pending:
+            f = self.collect(j)
+            if on_frame:
+                on_frame(j, f)

@@ -110,7 +110,7 @@ typedef struct hmrm_stats {
 	/* traversal diagnostics of the production kernel (0 for HMRM_KERNEL=simple)      */
 	uint64_t leap_attempts; /* pyramid look-ups tried                                 */
 	uint64_t leaps;         /* ... that ended in an exact jump                        */
-	uint64_t groups;        /* speculative 4-step groups executed                     */
+	uint64_t groups;        /* speculative groups executed (4 positions each; 6 in the plain-groups kernel) */
 	uint64_t leaped_steps;  /* ray-steps covered by jumps (part of `steps`)           */
 } hmrm_stats;
 
@@ -255,10 +255,10 @@ int hmrm_debug_rcp_error(int32_t mode, uint64_t count, uint64_t seed, int32_t ex
                          double *max_rel_err, uint64_t *hist64);
 
 /* Test hook, needs no GPU: the window-maximum pyramid layout hmrm_scene_create chooses for a map_w x map_h map
- * (row pitch in windows, log2 of the plane pitch, number of levels).  Returns 1 when the production kernel's
- * 32-bit look-up offsets cover every plane, 0 when they do not (very oblong maps near the 2^29-cell limit, e.g.
- * 16385 x 32766): such a scene is rendered by the literal loop (main/hmap.cpp:1000-1038 as written), nearest
- * sampling only.  Negative = HMRM_E_ARG. */
+ * (row pitch in windows, log2 of the plane pitch, number of levels).  Returns 1 when 32-bit BYTE offsets would cover
+ * every plane, 0 when only 64-bit ones do (very oblong maps near the 2^29-cell limit, e.g. 16385 x 32766).  The
+ * production kernel forms the offsets in 64 bits since round 5, so both kinds of map render with it (round 4 sent the
+ * second kind through the literal loop, main/hmap.cpp:1000-1038 as written, 85 x slower).  Negative = HMRM_E_ARG. */
 int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_t *plane_shift, int32_t *levels);
 
 /* Which kernel full frames of this scene are rendered with: 0 = the production kernel (speculative groups + exact

@@ -88,6 +88,17 @@ for k in range(count):
         print("MISMATCH seed", seed, "map", (mw, mh), "gw", gw, "hi", hi, "kind", kind, "proj", cam.projection, "sd", repr(sd),
               "res", (cam.width, cam.height), "sampling", cam.sampling, "capped", capped, st.capped,
               "steps diff", int((steps.astype(np.int64) != osteps).sum()), "px diff", int((fb != ofb).any(axis=2).sum()), flush=True)
+        # what differs, and does it differ again?  (a mismatch that a second render of the same scene does not repeat is a race,
+        # not arithmetic)
+        for (r, c) in np.argwhere((fb != ofb).any(axis=2))[:4]:
+            print("   stats frame px", (int(c), int(r)), "gpu", fb[r, c].tolist(), "oracle", ofb[r, c].tolist(), "steps", int(steps[r, c]), int(osteps[r, c]), flush=True)
+        plain = scene.render(cam)
+        for (r, c) in np.argwhere((plain != ofb).any(axis=2))[:4]:
+            print("   plain frame px", (int(c), int(r)), "gpu", plain[r, c].tolist(), "oracle", ofb[r, c].tolist(), flush=True)
+        for rep in range(2):
+            fb2, _, steps2, _ = scene.render_stats(cam, per_pixel=True, allow_capped=True)
+            print("   rendered again: px diff", int((fb2 != ofb).any(axis=2).sum()), "steps diff", int((steps2.astype(np.int64) != osteps).sum()),
+                  "plain px diff", int((scene.render(cam) != ofb).any(axis=2).sum()), flush=True)
     leaped += st.leaped_steps
     jumps += st.leaps
     done += 1

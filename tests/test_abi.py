@@ -141,9 +141,10 @@ def test_header_is_c_and_links_from_a_c_program(hmrm, tmp_path):
 
 
 def test_pyramid_layout_and_the_32_bit_offset_bound(hmrm):
-    """k_render_fast forms a pyramid look-up's byte offset in 32 bits, so a scene whose
-    (levels + 1) planes of 2^shift floats exceed 2^32 bytes must not be rendered by it.  hmrm_scene_create routes such
-    a scene (very oblong maps near the 2^29-cell limit) to the literal loop; this checks the layout rule without a GPU."""
+    """The pyramid layout rule, without a GPU.  Round 4: k_render_fast formed a look-up's byte offset in 32 bits and
+    scenes whose (levels + 1) planes of 2^shift floats exceed 2^32 bytes -- very oblong maps near the 2^29-cell limit -- went to
+    the literal loop.  Round 5: the ELEMENT index is 32 bits (checked here: it always fits) and the byte offset 64, so every
+    legal map renders with the production kernel (GPU: test_pyramid_planes_beyond_4_gib_of_offsets)."""
     for w, h in [(1, 1), (256, 256), (4096, 4096), (8192, 8192), (23170, 23170), (1 << 24, 1), (1, 1 << 24), (16384, 32768),
                  (16385, 32766), (32766, 16385), (3, 178956970), (536870912, 1)]:
         row, shift, levels, fits = hmrm.mip_layout(w, h)
@@ -152,6 +153,7 @@ def test_pyramid_layout_and_the_32_bit_offset_bound(hmrm):
         need = ((h + 1) // 2 - 1) * row + (w + 1) // 2  # last element of level 0's plane + 1
         assert (1 << shift) >= need and (shift == 0 or (1 << (shift - 1)) < need)
         assert fits == (((levels + 1) << shift) * 4 <= 1 << 32), (w, h, shift)
+        assert ((levels + 1) << shift) <= 1 << 32, (w, h, shift)  # the kernel's 32-bit element index covers every plane
     assert hmrm.mip_layout(4096, 4096)[3] and hmrm.mip_layout(23170, 23170)[3]  # every square map up to the cell limit fits
     assert not hmrm.mip_layout(16385, 32766)[3]  # the advisor's example: plane shift 28
     import pytest as _pytest
@@ -159,3 +161,21 @@ def test_pyramid_layout_and_the_32_bit_offset_bound(hmrm):
         hmrm.mip_layout(0, 5)
     with _pytest.raises(hmrm.HmrmError):
         hmrm.mip_layout(32768, 32768)  # more than 2^29 cells: hmrm_scene_create refuses the map
+
+
+def test_gfx950_has_no_texture_path(tmp_path):
+    """north_star names a 2D texture object for the heightmap; gfx950 (CDNA4) has no image instructions and hipcc refuses the
+    texture API for the target -- which is why every height / pyramid read of the kernels is a plain load
+    (profiles/r05_texture_ab.txt).  Should a later toolchain accept this kernel, the A/B VERDICT r04 #6 asked for becomes possible."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    src = tmp_path / "tex.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n"
+                   "__global__ void k(hipTextureObject_t t, float *out, int w) {\n"
+                   "\tint i = blockIdx.x * blockDim.x + threadIdx.x;\n"
+                   "\tout[i] = tex2D<float>(t, (float)(i % w), (float)(i / w));\n}\n")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", str(tmp_path / "tex.o")], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "image/texture API not supported on the device" in r.stderr, r.stderr[-600:]

@@ -173,3 +173,105 @@ def test_orbit_frames_of_rank_matches_the_c_abi():
         if 64 % world == 0:
             assert sorted(seen) == list(range(64))
     assert hmrm.orbit_frame_owner(5, 0) == -1 and hmrm.orbit_frame_owner(-1, 4) == -1
+
+
+def _pattern_frame(k, height, width):
+    """A frame that names its frame index and row in every pixel (stand-in renderer of the pipeline tests)."""
+    rows = np.arange(height, dtype=np.int64)[:, None]
+    cols = np.arange(width, dtype=np.int64)[None, :]
+    f = np.zeros((height, width, 4), dtype=np.uint8)
+    f[..., 0] = (rows * 7 + k * 13) & 255
+    f[..., 1] = (cols * 3 + k) & 255
+    f[..., 2] = (rows >> 8) & 255
+    f[..., 3] = 255
+    return f
+
+
+def _pipeline_worker(rank, world, port, height, band_rows, depth, chunks, rotate, frames, result_dir):
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    strips = importlib.import_module("heightmap-ray-marcher_amd.strips")
+    width = 19
+    plan = strips.BandPlan(height=height, width=width, band_rows=band_rows, world=world)
+    pipe = strips.StripPipeline(plan, rank, dist, torch, "cpu", depth=depth, chunks=chunks, rotate_root=rotate)
+
+    def render_rows_of(k):
+        full = _pattern_frame(k, height, width)
+
+        def render_rows(strip, band_rows_, band_index, band_count):
+            assert band_rows_ == band_rows and band_count == world * chunks and band_index % world == rank
+            vplan = strips.BandPlan(height=height, width=width, band_rows=band_rows, world=band_count)
+            host = strip.numpy()
+            host[:] = 0xEE  # (stale bytes of the frame that used this buffer before must not survive)
+            for j, b in enumerate(vplan.bands_of(band_index)):
+                g0, g1 = b * band_rows, min((b + 1) * band_rows, height)
+                host[j * band_rows:j * band_rows + (g1 - g0)] = full[g0:g1]
+            if (k + rank) % 3 == 0:
+                time.sleep(0.01)  # ranks drift apart: a frame's gather overlaps the next frame's render on the faster rank
+        return render_rows
+
+    got = {}
+    pipe.run(range(frames), render_rows_of, on_frame=lambda k, f: got.__setitem__(k, None if f is None else f.numpy().copy()))
+    ok = True
+    for k in range(frames):
+        root = (k % world) if rotate else 0
+        if rank == root:
+            ok = ok and got[k] is not None and np.array_equal(got[k], _pattern_frame(k, height, width))
+        else:
+            ok = ok and got[k] is None
+    # the double buffer's order: frame k + depth is rendered only after frame k has been drained, and with depth > 1 frame
+    # k + 1 is rendered BEFORE frame k is drained (that is the overlap)
+    pos = {(what, k, c): i for i, (what, k, c) in enumerate(pipe.log)}
+    for k in range(frames - depth):
+        ok = ok and pos[("drained", k, -1)] < pos[("rendered", k + depth, 0)]
+    if depth > 1 and frames > 1:
+        ok = ok and pos[("rendered", 1, 0)] < pos[("drained", 0, -1)]
+    # chunks: the gather of a chunk is issued before the next chunk is rendered (the root starts receiving early)
+    for c in range(chunks - 1):
+        ok = ok and pos[("gather issued", 0, c)] < pos[("rendered", 0, c + 1)]
+    t = torch.tensor([int(ok)])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        with open(os.path.join(result_dir, "ok.txt"), "w") as f:
+            f.write(str(int(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height,band_rows,depth,chunks,rotate", [(47, 8, 2, 1, False), (64, 4, 2, 3, True), (33, 16, 3, 2, True), (40, 8, 1, 2, False)])
+def test_strip_pipeline_world2_gloo(tmp_path, height, band_rows, depth, chunks, rotate):
+    """StripPipeline over two gloo ranks: every frame arrives whole on its root (rank 0, or k mod world with a rotating
+    root), no buffer is reused before its gather is done, and the next frame is rendered while the previous one's strips
+    are still being gathered."""
+    import torch.multiprocessing as mp
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), height, band_rows, depth, chunks, rotate, 7, str(tmp_path)), nprocs=2, join=True)
+    assert open(str(tmp_path / "ok.txt")).read() == "1"
+
+
+def test_strip_pipeline_single_rank():
+    import torch
+    strips = importlib.import_module("heightmap-ray-marcher_amd.strips")
+    height, width, band = 37, 11, 8
+    plan = strips.BandPlan(height=height, width=width, band_rows=band, world=1)
+    pipe = strips.StripPipeline(plan, 0, None, torch, "cpu", depth=2, chunks=2)
+
+    def render_rows_of(k):
+        full = _pattern_frame(k, height, width)
+
+        def render_rows(strip, band_rows_, band_index, band_count):
+            vplan = strips.BandPlan(height=height, width=width, band_rows=band, world=band_count)
+            host = strip.numpy()
+            for j, b in enumerate(vplan.bands_of(band_index)):
+                g0, g1 = b * band, min((b + 1) * band, height)
+                host[j * band:j * band + (g1 - g0)] = full[g0:g1]
+        return render_rows
+    seen = []
+    pipe.run(range(5), render_rows_of, on_frame=lambda k, f: seen.append(np.array_equal(f.numpy(), _pattern_frame(k, height, width))))
+    assert seen == [True] * 5
+    with pytest.raises(AssertionError):
+        pipe.submit(0, render_rows_of(0)); pipe.submit(2, render_rows_of(2))  # frame 0 not collected: its buffers are still in use
