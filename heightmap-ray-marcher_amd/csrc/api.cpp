@@ -110,7 +110,6 @@ Knobs read_knobs() {
 
 using hmrm::kCostRows;
 constexpr int kFrameSlots = 64;  // cached per-frame records (and spherical tables) per stream: a 64-frame orbit fits
-constexpr int kOrderSamples = 2;   // measured launches per trial order (one launch's makespan wobbles by a few per cent)
 constexpr int kMaxMeasRows = 512;  // tile rows (8192 frame rows) a launch order is calibrated for; taller frames keep the rotation
 constexpr int kProbeAfterFrames = 6; // full frames of never-repeating cameras before the scene's shadow probe
 constexpr int kMaxStreamCtx = 32; // streams a scene keeps launch state for (more: the least recently used one is recycled, with a stream sync)
@@ -129,24 +128,8 @@ struct FrameSlot {
 	double *d_tables = nullptr;  // spherical sin/cos tables: this slot's piece of the context's arenas
 	double *h_tables = nullptr;  // pinned staging, likewise
 	hipEvent_t uploaded = nullptr; // after the H2D copy out of h_tables: the host may rewrite them then
-	// Launch order calibrated by measurement (plan_order_from_measurement below): a short list of trial orders, each
-	// timed by one measured full-frame launch -- [0] the rotation, then the model's plan and a generic head / tail /
-	// middle split of the measured hot range -- after which the one with the shortest measured makespan stays.
-	// The last candidate is not an order but the OTHER KERNEL: the plain speculative groups without leaps.  On content
-	// that admits no jumps (needles on a plateau, white noise seen from a perspective camera: profiles/r04_content.txt)
-	// the leap kernel's attempts are pure overhead, up to 15 %; a camera that is rendered repeatedly finds that out by
-	// measurement and stays with the faster kernel (which must win by 3 %).  Same pixels either way.
-	struct OrderTrial {
-		int n = 0, b[3] = {0, 0, 0}, c[3] = {0, 0, 0}; // pieces (n = 0: the plain rotation)
-		bool group = false;                            // the trial runs the plain 4-step groups (no leaps), rotation order
-		double makespan = 0.0;                         // measured, ticks (the shorter of kOrderSamples launches); 0 = not yet
-		int samples = 0;
-	};
-	OrderTrial trials[4];
-	int n_trials = 1;              // known so far (the candidates are made from the rotation's records)
-	int trial_in_flight = -1;      // the trial whose measured launch has not been read yet
-	int order_best = -1;           // settled: index into trials (-1: still calibrating, the rotation is used)
-	uint32_t uses = 0;             // full-frame launches of this record
+	// launch order calibrated by measurement, and -- for one record per scene -- the kernel probe: launch_order.hpp
+	hmrm::OrderCalibration cal;
 	int meas_rows = 0;             // tile rows of the measured launch in flight
 	hipEvent_t measured = nullptr; // after the read-back of a measured launch
 };
@@ -174,6 +157,7 @@ struct StreamCtx {
 	unsigned long long capped_seen = 0; // value of [2] the host has already reported
 	// recorded behind every launch: what a recycled context waits for (the caller's stream handle may be gone by then)
 	hipEvent_t last_launch = nullptr;
+	bool launched = false; // ... has been recorded at least once
 };
 
 // One slot of the asynchronous read-back ring (hmrm_render_begin/_wait/_release): a device frame
@@ -211,8 +195,8 @@ struct hmrm_scene {
 	uint8_t *d_rgb = nullptr;   // W*H*3  base_heightmap_buf (hmap.cpp:51)
 	uint32_t *d_cmap = nullptr; // W*H    colormap_buf as packed RGBA (hmap.cpp:59)
 	double *d_thr = nullptr;    // W*H    heightmap_buf[i] + min_height
-	float *d_thr32 = nullptr;   // W*H    the same rounded to float ("float heights" mode), built on first use
-	bool thr32_valid = false;
+	float *d_thr32 = nullptr;   // W*H    the same rounded to float, right behind d_thr in the same allocation: the groups' filtered
+	                            //        compare (render_fast.hip) and the "float heights" mode read it; rebuilt with every update
 	double thr_max = 0.0;
 	double thr_max_bil = 0.0; // whole-map bound of the interpolated thresholds (bilinear mode)
 	bool bil_valid = false;
@@ -249,25 +233,27 @@ struct hmrm_scene {
 		hmrm_camera cam;
 		hmrm_scene_params params;
 		uint64_t thr_max_bits;
-		int n, b[3], c[3];
-		bool group;
+		hmrm::OrderTrial order;
 	};
-	// Which kernel suits the scene's content is probed ONCE per scene and height update, by the first camera that gets
-	// calibrated (two launches of the plain groups cost 3-6 ms on a 4K frame where leaps pay: too much to spend per
-	// camera); every other camera -- a moving one is never calibrated -- renders with the kernel that probe chose.
-	bool kernel_probed = false;
-	bool last_settled_group = false;
+	// Which kernel suits the scene's content (launch_order.hpp KernelChoice): probed ONCE per scene and height update, by
+	// the first camera that gets calibrated (two launches of the plain groups cost 3-6 ms on a 4K frame where leaps pay: too
+	// much to spend per camera); every other camera -- a moving one is never calibrated -- renders with that verdict.
+	hmrm::KernelChoice choice;
 	// ... and a scene whose cameras never repeat (a moving camera: nothing is ever calibrated) is probed on its
 	// kProbeAfterFrames-th full frame instead: that frame is launched twice into the same buffer -- production kernel,
 	// then plain groups; same pixels -- both measured like a calibration launch, and the verdict is read when the second
-	// has finished (any later launch looks).  One 3-6 ms hiccup per scene on a 4K frame.
-	uint32_t unprobed_frames = 0;
+	// has finished (any later launch looks).  One 3-6 ms hiccup per scene on a 4K frame; a caller that cannot have it
+	// passes HMRM_NO_PROBE with its ticketed frames (hmrm.h).
 	bool probe_pending = false;
 	uint32_t probe_epoch = 0, probe_epoch_launched = 0; // (a height update or a knob reload voids a probe in flight)
 	int probe_rows = 0;
 	StreamCtx *probe_ctx = nullptr;
 	hipEvent_t probe_done = nullptr;
 	unsigned long long *h_probe = nullptr, *h_probe_dev = nullptr; // pinned: 2 x (2 x kMaxMeasRows) words
+	// A measured launch (calibration trial or probe) wants the chip to itself: it is issued only when the scene's other
+	// streams are idle, and launches on those streams wait for it (overlapping lanes inflated or deflated trials).
+	hipEvent_t measure_fence = nullptr;
+	StreamCtx *measure_fence_ctx = nullptr;
 	std::vector<SettledOrder> settled;
 };
 
@@ -315,6 +301,7 @@ int ctx_for(hmrm_scene *s, hipStream_t stream, StreamCtx **out) {
 		// may have been destroyed since (no call may name it any more): wait on the context's own event instead
 		(void)hipEventSynchronize(s->ctxs[victim]->last_launch);
 		if (s->probe_ctx == s->ctxs[victim]) s->probe_ctx = nullptr;
+		if (s->measure_fence_ctx == s->ctxs[victim]) s->measure_fence_ctx = nullptr;
 		destroy_ctx(s->ctxs[victim]);
 		s->ctxs.erase(s->ctxs.begin() + (long)victim);
 	}
@@ -388,12 +375,8 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 				if (!sl.valid) break;
 			}
 		slot->valid = false;
-		if (slot->trial_in_flight >= 0) HIP_TRY(hipEventSynchronize(slot->measured)); // (its records are about to be reused)
-		slot->trial_in_flight = -1;
-		slot->order_best = -1;
-		slot->n_trials = 1;
-		for (FrameSlot::OrderTrial &t : slot->trials) t = FrameSlot::OrderTrial();
-		slot->uses = 0;
+		if (slot->cal.in_flight >= 0) HIP_TRY(hipEventSynchronize(slot->measured)); // (its records are about to be reused)
+		slot->cal.reset();
 		hmrm::HostCamera hc;
 		to_host_camera(cam, &hc);
 		double *cc = nullptr, *cs = nullptr, *rs = nullptr, *rc = nullptr;
@@ -470,15 +453,6 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 			const int rc2 = ensure_bilinear_pyramid(s);
 			if (rc2 != HMRM_OK) return rc2;
 		}
-		if (cam->sampling == HMRM_NEAREST_F32 && !s->thr32_valid) {
-			// float copy of the threshold table; made on the scene's stream and waited for, the
-			// launch may be on another one
-			const int64_t n = (int64_t)s->map_w * s->map_h;
-			if (!s->d_thr32) HIP_TRY(hipMalloc((void **)&s->d_thr32, (size_t)n * sizeof(float)));
-			HIP_TRY(hmrm::launch_thr_to_float(s->d_thr, s->d_thr32, n, s->stream));
-			HIP_TRY(hipStreamSynchronize(s->stream));
-			s->thr32_valid = true;
-		}
 		// (informational: the kernel reads the whole-map bound from the pyramid's top plane, rounded up to
 		// float like every window maximum -- which also bounds the float copy of a threshold)
 		fr.thr_max = cam->sampling == HMRM_BILINEAR ? s->thr_max_bil : s->thr_max;
@@ -497,11 +471,7 @@ int prepare_frame(hmrm_scene *s, StreamCtx *c, const hmrm_camera *cam, hmrm::Dev
 		for (size_t k = s->settled.size(); k-- > 0;) { // (newest first)
 			const hmrm_scene::SettledOrder &so = s->settled[k];
 			if (memcmp(&so.cam, cam, sizeof *cam) != 0 || memcmp(&so.params, &s->params, sizeof s->params) != 0 || so.thr_max_bits != thr_bits) continue;
-			slot->trials[1].n = so.n;
-			slot->trials[1].group = so.group;
-			for (int j = 0; j < 3; ++j) { slot->trials[1].b[j] = so.b[j]; slot->trials[1].c[j] = so.c[j]; }
-			slot->n_trials = 2;
-			slot->order_best = 1;
+			slot->cal.adopt(so.order);
 			break;
 		}
 	}
@@ -528,166 +498,96 @@ int ensure_meas(StreamCtx *c) {
 	return HMRM_OK;
 }
 
-// One frame (or row strip) on the context's stream.  Kernel variant: "leap" (default; speculative
-// groups + exact leaps), "group" (speculative groups only), "simple" (the literal
-// one-step-at-a-time loop, kept for A/B runs and as an in-library cross-check).  All produce
-// identical pixels and counts.
-int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot *slot, const hmrm::RowMap &rows,
-                 uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats) {
-	hmrm::RowMap rows_in_order = rows;
-	bool measure_now = false;
-	int tiles_y = 0, trial_now = -1;
-	bool use_group = false; // render with the plain groups (the calibration measured them faster on this content)
-	bool shadow_probe = false;
-	{
-		int tile_w = 1, tile_h = 1;
-		hmrm::render_tile_shape(&tile_w, &tile_h);
-		tiles_y = (rows.local_rows + tile_h - 1) / tile_h;
-		const bool pieces = s->knobs.seg_n > 0 && rows.band_rows == 0 && rows.row_begin == 0;
-		const int rot = hmrm::choose_tile_rot(s->knobs.tile_order, slot->row_cost, rows, tile_h);
-		int nb = pieces ? s->knobs.seg_n : 0, b[3] = {s->knobs.seg_b[0], s->knobs.seg_b[1], s->knobs.seg_b[2]},
-		    c3[3] = {s->knobs.seg_c[0], s->knobs.seg_c[1], s->knobs.seg_c[2]};
-		// calibration (see plan_order_from_measurement): full frames of the production kernel only
-		const bool eligible = !pieces && !stats && s->knobs.tile_order && s->knobs.order_mode == 2 && s->knobs.kernel != 2 &&
-		                      rows.band_rows == 0 && rows.row_begin == 0 && rows.local_rows == f.screen_h && tiles_y >= 12 &&
-		                      tiles_y <= kMaxMeasRows && s->map_w < (1 << 24) && s->map_h < (1 << 24);
-		if (eligible) {
-			++slot->uses;
-			const size_t idx = (size_t)(slot - c->slots);
-			unsigned long long *h_rec = c->h_meas ? c->h_meas + idx * 2 * kMaxMeasRows : nullptr;
-			if (slot->trial_in_flight >= 0 && slot->meas_rows == tiles_y && hipEventQuery(slot->measured) == hipSuccess) {
-				FrameSlot::OrderTrial &t = slot->trials[slot->trial_in_flight];
-				const double span = std::max(1.0, hmrm::measured_makespan(h_rec, tiles_y));
-				t.makespan = t.samples == 0 ? span : std::min(t.makespan, span);
-				++t.samples;
-				if (slot->trial_in_flight == 0 && t.samples == 1) { // the rotation's records: make the candidates
-					FrameSlot::OrderTrial &plan = slot->trials[slot->n_trials];
-					plan.n = hmrm::plan_order_from_measurement(h_rec, tiles_y, rot, plan.b, plan.c);
-					if (plan.n > 0) ++slot->n_trials;
-					FrameSlot::OrderTrial &split = slot->trials[slot->n_trials];
-					split.n = hmrm::split_hot_range(h_rec, tiles_y, rot, 0.45, 0.25, split.b, split.c);
-					const bool same = split.n == plan.n && slot->n_trials > 1 && memcmp(split.b, plan.b, sizeof split.b) == 0 &&
-					                  memcmp(split.c, plan.c, sizeof split.c) == 0;
-					if (split.n > 0 && !same) ++slot->n_trials;
-					if (s->knobs.kernel == 0 && s->knobs.try_group && !s->kernel_probed) { // the other kernel, under the rotation
-						s->kernel_probed = true; // (this record's trials hold the probe: one camera per scene)
-						FrameSlot::OrderTrial &g = slot->trials[slot->n_trials];
-						g = FrameSlot::OrderTrial();
-						g.group = true;
-						++slot->n_trials;
-					}
-				}
-				if (s->knobs.order_verbose) {
-					fprintf(stderr, "hmrm order: trial %d of %d tile rows measured, makespan %.1f us:", slot->trial_in_flight, tiles_y, t.makespan / 100.0);
-					for (int k = 0; k < t.n; ++k) fprintf(stderr, " [%d,%d)", t.b[k], t.b[k] + t.c[k]);
-					fprintf(stderr, "%s\n", t.group ? " plain groups, rotation" : (t.n ? "" : " rotation"));
-				}
-				slot->trial_in_flight = -1;
-				int next = -1;
-				for (int k = 0; k < slot->n_trials; ++k)
-					if (slot->trials[k].samples < kOrderSamples) { next = k; break; }
-				if (next < 0) { // all timed: the shortest stays; another order must beat the rotation by 1 %
-					int best = 0;
-					for (int k = 1; k < slot->n_trials; ++k)
-						if (!slot->trials[k].group && slot->trials[k].makespan < 0.99 * slot->trials[0].makespan && slot->trials[k].makespan < slot->trials[best].makespan) best = k;
-					for (int k = 1; k < slot->n_trials; ++k) // (the other kernel must beat the best order of this one by 3 %)
-						if (slot->trials[k].group && slot->trials[k].makespan < 0.97 * slot->trials[best].makespan) best = k;
-					slot->order_best = best;
-					for (int k = 1; k < slot->n_trials; ++k)
-						if (slot->trials[k].group) s->last_settled_group = slot->trials[best].group; // (the probing record decides)
-					if (s->knobs.order_verbose) fprintf(stderr, "hmrm order: settled on trial %d\n", best);
-					hmrm_scene::SettledOrder so{};
-					so.cam = slot->cam;
-					so.params = slot->params;
-					so.thr_max_bits = slot->thr_max_bits;
-					so.n = slot->trials[best].n;
-					so.group = slot->trials[best].group;
-					for (int k = 0; k < 3; ++k) { so.b[k] = slot->trials[best].b[k]; so.c[k] = slot->trials[best].c[k]; }
-					if (s->settled.size() >= 256) s->settled.erase(s->settled.begin());
-					s->settled.push_back(so);
-				}
-			}
-			// (one measured launch per context at a time: they share the device records)
-			if (c->meas_owner && (c->meas_owner->trial_in_flight < 0 || hipEventQuery(c->meas_owner->measured) == hipSuccess))
-				c->meas_owner = nullptr;
-			int use = slot->order_best >= 0 ? slot->order_best : 0;
-			if (slot->order_best < 0 && slot->trial_in_flight < 0 && slot->uses >= 2 && c->meas_owner == nullptr) {
-				for (int k = 0; k < slot->n_trials; ++k)
-					if (slot->trials[k].samples < kOrderSamples) { use = k; measure_now = true; break; }
-				if (measure_now) trial_now = use;
-			}
-			nb = slot->trials[use].n;
-			for (int k = 0; k < nb; ++k) { b[k] = slot->trials[use].b[k]; c3[k] = slot->trials[use].c[k]; }
-			// the probing record times both kernels; everybody else renders with the one the scene's probe chose
-			bool probing = false;
-			for (int k = 1; k < slot->n_trials; ++k) probing = probing || slot->trials[k].group;
-			use_group = (probing && (slot->order_best >= 0 || measure_now)) ? slot->trials[use].group : s->last_settled_group;
-		} else if (!stats && s->knobs.kernel == 0 && s->knobs.try_group) {
-			use_group = s->last_settled_group; // strips, bands, small frames: the scene's last measured choice
+// ---- measured launches: the HIP side of launch_order.hpp's calibration ----
+// Is nothing of the scene running on another of its own streams?  (A measured launch wants the chip to itself.)
+bool others_idle(hmrm_scene *s, StreamCtx *c) {
+	for (StreamCtx *o : s->ctxs)
+		if (o != c && o->scene_owned && o->launched && hipEventQuery(o->last_launch) != hipSuccess) return false;
+	return true;
+}
+
+// A measured launch of another context is still running: this context's launch waits for it (stream order, no host wait).
+int wait_for_measure_fence(hmrm_scene *s, StreamCtx *c) {
+	if (!s->measure_fence_ctx || s->measure_fence_ctx == c) return HMRM_OK;
+	if (hipEventQuery(s->measure_fence) == hipSuccess) s->measure_fence_ctx = nullptr;
+	else HIP_TRY(hipStreamWaitEvent(c->stream, s->measure_fence, 0));
+	return HMRM_OK;
+}
+
+int raise_measure_fence(hmrm_scene *s, StreamCtx *c) {
+	if (!s->measure_fence) HIP_TRY(hipEventCreateWithFlags(&s->measure_fence, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(s->measure_fence, c->stream));
+	s->measure_fence_ctx = c;
+	return HMRM_OK;
+}
+
+// A finished measured launch of this record is folded into its calibration; a calibration that settles is published.
+void poll_measured(hmrm_scene *s, StreamCtx *c, FrameSlot *slot, int tiles_y, int rot) {
+	if (slot->cal.in_flight >= 0 && slot->meas_rows == tiles_y && hipEventQuery(slot->measured) == hipSuccess) {
+		const int trial = slot->cal.in_flight;
+		const unsigned long long *h_rec = c->h_meas + (size_t)(slot - c->slots) * 2 * kMaxMeasRows;
+		const bool settled = slot->cal.on_measured(h_rec, tiles_y, rot, s->knobs.kernel == 0 && s->knobs.try_group, s->choice);
+		if (s->knobs.order_verbose) {
+			const hmrm::OrderTrial &t = slot->cal.trials[trial];
+			fprintf(stderr, "hmrm order: trial %d of %d tile rows measured, makespan %.1f us:", trial, tiles_y, t.makespan / 100.0);
+			for (int k = 0; k < t.n; ++k) fprintf(stderr, " [%d,%d)", t.b[k], t.b[k] + t.c[k]);
+			fprintf(stderr, "%s\n", t.group ? " plain groups, rotation" : (t.n ? "" : " rotation"));
+			if (settled) fprintf(stderr, "hmrm order: settled on trial %d\n", slot->cal.best);
 		}
-		hmrm::set_tile_order(&rows_in_order, tiles_y, rot, nb, b, c3);
-		// ---- the scene's shadow probe (cameras that never repeat): verdict of one in flight, start of a new one
-		if (s->probe_pending && hipEventQuery(s->probe_done) == hipSuccess) {
-			s->probe_pending = false;
-			if (s->probe_ctx) s->probe_ctx->probe_in_flight = false;
-			if (s->probe_epoch_launched == s->probe_epoch) {
-				const double leap_span = std::max(1.0, hmrm::measured_makespan(s->h_probe, s->probe_rows));
-				const double group_span = std::max(1.0, hmrm::measured_makespan(s->h_probe + 2 * kMaxMeasRows, s->probe_rows));
-				s->last_settled_group = group_span < 0.97 * leap_span;
-				if (s->knobs.order_verbose)
-					fprintf(stderr, "hmrm probe: production kernel %.1f us, plain groups %.1f us -> %s\n", leap_span / 100.0, group_span / 100.0,
-					        s->last_settled_group ? "plain groups" : "production kernel");
-			}
+		if (settled) {
+			if (s->settled.size() >= 256) s->settled.erase(s->settled.begin());
+			s->settled.push_back(hmrm_scene::SettledOrder{slot->cam, slot->params, slot->thr_max_bits, slot->cal.trials[slot->cal.best]});
 		}
-		if (eligible && !measure_now && s->knobs.kernel == 0 && s->knobs.try_group && !s->kernel_probed && !s->probe_pending &&
-		    c->meas_owner == nullptr && slot->trial_in_flight < 0 && ++s->unprobed_frames >= (uint32_t)kProbeAfterFrames)
-			shadow_probe = true;
 	}
-	if (c->probe_in_flight && measure_now) { // (the probe holds this context's device records: this trial waits a launch)
-		measure_now = false;
-		trial_now = -1;
-		use_group = s->last_settled_group;
+	// (one measured launch per context at a time: they share the device records)
+	if (c->meas_owner && (c->meas_owner->cal.in_flight < 0 || hipEventQuery(c->meas_owner->measured) == hipSuccess)) c->meas_owner = nullptr;
+}
+
+// The verdict of a shadow probe in flight, once both of its launches have finished.
+void poll_shadow_probe(hmrm_scene *s) {
+	if (!s->probe_pending || hipEventQuery(s->probe_done) != hipSuccess) return;
+	s->probe_pending = false;
+	if (s->probe_ctx) s->probe_ctx->probe_in_flight = false;
+	if (s->probe_epoch_launched != s->probe_epoch) return; // (the heights or the knobs changed meanwhile)
+	hmrm::fold_shadow_probe(s->choice, s->h_probe, s->h_probe + 2 * kMaxMeasRows, s->probe_rows);
+	if (s->knobs.order_verbose)
+		fprintf(stderr, "hmrm probe: production kernel %.1f us, plain groups %.1f us -> %s\n", hmrm::measured_makespan(s->h_probe, s->probe_rows) / 100.0,
+		        hmrm::measured_makespan(s->h_probe + 2 * kMaxMeasRows, s->probe_rows) / 100.0, s->choice.use_group ? "plain groups" : "production kernel");
+}
+
+// The shadow probe: this frame twice into the same buffer -- production kernel, then the plain groups; same pixels, the
+// second launch's capped rays counted apart -- both measured like a calibration launch.
+int launch_shadow_probe(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const hmrm::RowMap &rows_in_order, int tiles_y,
+                        uint32_t *d_out, int64_t out_stride_px) {
+	if (!s->h_probe) {
+		HIP_TRY(hipHostMalloc((void **)&s->h_probe, (size_t)4 * kMaxMeasRows * sizeof(unsigned long long), hipHostMallocMapped));
+		HIP_TRY(hipHostGetDevicePointer((void **)&s->h_probe_dev, s->h_probe, 0));
+		HIP_TRY(hipEventCreateWithFlags(&s->probe_done, hipEventDisableTiming));
 	}
-	if (shadow_probe) {
-		if (!s->h_probe) {
-			HIP_TRY(hipHostMalloc((void **)&s->h_probe, (size_t)4 * kMaxMeasRows * sizeof(unsigned long long), hipHostMallocMapped));
-			HIP_TRY(hipHostGetDevicePointer((void **)&s->h_probe_dev, s->h_probe, 0));
-			HIP_TRY(hipEventCreateWithFlags(&s->probe_done, hipEventDisableTiming));
-		}
-		{
-			const int rc_m = ensure_meas(c);
-			if (rc_m) return rc_m;
-		}
-		hmrm::RowMap measured = rows_in_order;
-		measured.measure = c->d_meas;
-		for (int pass = 0; pass < 2; ++pass) { // production kernel, then the plain groups: the same frame into the same buffer
-			HIP_TRY(hmrm::launch_measure_init(measured.measure, tiles_y, c->stream));
-			HIP_TRY(hmrm::launch_render_fast(f, measured, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
-			                                 c->d_counters + (pass ? 8 : 0), nullptr, nullptr, false, pass == 0, c->stream));
-			HIP_TRY(hmrm::launch_measure_readback(measured.measure, s->h_probe_dev + (size_t)pass * 2 * kMaxMeasRows, tiles_y, c->stream));
-		}
-		HIP_TRY(hipEventRecord(s->probe_done, c->stream));
-		s->probe_pending = true;
-		s->kernel_probed = true;
-		s->probe_rows = tiles_y;
-		s->probe_epoch_launched = s->probe_epoch;
-		s->probe_ctx = c;
-		c->probe_in_flight = true;
-		if (!c->scene_owned) HIP_TRY(hipEventRecord(c->last_launch, c->stream));
-		return HMRM_OK;
+	const int rc_m = ensure_meas(c);
+	if (rc_m) return rc_m;
+	hmrm::RowMap measured = rows_in_order;
+	measured.measure = c->d_meas;
+	for (int pass = 0; pass < 2; ++pass) {
+		HIP_TRY(hmrm::launch_measure_init(measured.measure, tiles_y, c->stream));
+		HIP_TRY(hmrm::launch_render_fast(f, measured, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
+		                                 c->d_counters + (pass ? 8 : 0), nullptr, nullptr, false, pass == 0, c->stream));
+		HIP_TRY(hmrm::launch_measure_readback(measured.measure, s->h_probe_dev + (size_t)pass * 2 * kMaxMeasRows, tiles_y, c->stream));
 	}
-	if (measure_now) {
-		{
-			const int rc_m = ensure_meas(c);
-			if (rc_m) return rc_m;
-		}
-		if (!slot->measured) HIP_TRY(hipEventCreateWithFlags(&slot->measured, hipEventDisableTiming));
-		rows_in_order.measure = c->d_meas;
-		c->meas_owner = slot;
-		HIP_TRY(hmrm::launch_measure_init(rows_in_order.measure, tiles_y, c->stream));
-	}
-	// the production kernel indexes cells and windows with 24-bit multiplies (leap_common.hpp index_2d): a map
-	// with a side of 2^24 cells or more (then at most 32 cells the other way) goes through the literal loop
+	HIP_TRY(hipEventRecord(s->probe_done, c->stream));
+	s->probe_pending = true;
+	s->choice.probed = true;
+	s->probe_rows = tiles_y;
+	s->probe_epoch_launched = s->probe_epoch;
+	s->probe_ctx = c;
+	c->probe_in_flight = true;
+	return raise_measure_fence(s, c);
+}
+
+// The render kernel itself: the literal loop (HMRM_KERNEL=simple, or a map with a side of 2^24 cells or more -- the production
+// kernel indexes cells and windows with 24-bit multiplies, leap_common.hpp index_2d), else the production kernel or the plain groups.
+int launch_kernel(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const hmrm::RowMap &rows_in_order, uint32_t *d_out,
+                  int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats, bool use_group) {
 	const bool huge_side = s->map_w >= (1 << 24) || s->map_h >= (1 << 24);
 	if (huge_side && f.sampling != 0)
 		return fail(HMRM_E_ARG, "maps with a side of 2^24 cells or more support nearest sampling only");
@@ -699,15 +599,70 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 		HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
 		                                 c->d_counters, d_steps, d_entry, stats, leap, c->stream));
 	}
+	return HMRM_OK;
+}
+
+// One frame (or row strip) on the context's stream.  Kernel variant: "leap" (default; speculative
+// groups + exact leaps), "group" (speculative groups only), "simple" (the literal
+// one-step-at-a-time loop, kept for A/B runs and as an in-library cross-check).  All produce
+// identical pixels and counts.  `no_probe`: the caller cannot have this frame launched twice (HMRM_NO_PROBE).
+int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot *slot, const hmrm::RowMap &rows,
+                 uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats, bool no_probe = false) {
+	hmrm::RowMap rows_in_order = rows;
+	int tile_w = 1, tile_h = 1;
+	hmrm::render_tile_shape(&tile_w, &tile_h);
+	const int tiles_y = (rows.local_rows + tile_h - 1) / tile_h;
+	const bool pieces = s->knobs.seg_n > 0 && rows.band_rows == 0 && rows.row_begin == 0; // (HMRM_TILE_SEGMENTS: an explicit order)
+	const int rot = hmrm::choose_tile_rot(s->knobs.tile_order, slot->row_cost, rows, tile_h);
+	const bool may_probe = !stats && s->knobs.kernel == 0 && s->knobs.try_group;
+	// calibration (launch_order.hpp): full frames of the fast kernels only
+	const bool eligible = !pieces && !stats && s->knobs.tile_order && s->knobs.order_mode == 2 && s->knobs.kernel != 2 &&
+	                      rows.band_rows == 0 && rows.row_begin == 0 && rows.local_rows == f.screen_h && tiles_y >= 12 &&
+	                      tiles_y <= kMaxMeasRows && s->map_w < (1 << 24) && s->map_h < (1 << 24);
+	int rc = wait_for_measure_fence(s, c);
+	if (rc) return rc;
+	poll_shadow_probe(s);
+	hmrm::OrderTrial order; // (the rotation)
+	if (pieces) {
+		order.n = s->knobs.seg_n;
+		for (int k = 0; k < 3; ++k) { order.b[k] = s->knobs.seg_b[k]; order.c[k] = s->knobs.seg_c[k]; }
+	}
+	bool use_group = may_probe && s->choice.use_group; // strips, bands, small frames: the scene's verdict
+	bool measure_now = false;
+	if (eligible) {
+		poll_measured(s, c, slot, tiles_y, rot);
+		const bool quiet = c->meas_owner == nullptr && !c->probe_in_flight && others_idle(s, c);
+		const hmrm::LaunchPlan p = slot->cal.plan(quiet, s->choice);
+		order = slot->cal.trials[p.trial];
+		use_group = p.use_group;
+		measure_now = p.measure;
+		if (!measure_now && may_probe && !no_probe && quiet && !s->choice.probed && !s->probe_pending && slot->cal.in_flight < 0 &&
+		    ++s->choice.unprobed_frames >= (unsigned)kProbeAfterFrames) {
+			hmrm::set_tile_order(&rows_in_order, tiles_y, rot, order.n, order.b, order.c);
+			return launch_shadow_probe(s, c, f, rows_in_order, tiles_y, d_out, out_stride_px);
+		}
+	}
+	hmrm::set_tile_order(&rows_in_order, tiles_y, rot, order.n, order.b, order.c);
+	if (measure_now) {
+		if ((rc = ensure_meas(c))) return rc;
+		if (!slot->measured) HIP_TRY(hipEventCreateWithFlags(&slot->measured, hipEventDisableTiming));
+		rows_in_order.measure = c->d_meas;
+		c->meas_owner = slot;
+		HIP_TRY(hmrm::launch_measure_init(rows_in_order.measure, tiles_y, c->stream));
+	}
+	if ((rc = launch_kernel(s, c, f, rows_in_order, d_out, out_stride_px, d_steps, d_entry, stats, use_group))) return rc;
 	if (measure_now) {
 		const size_t idx = (size_t)(slot - c->slots);
 		HIP_TRY(hmrm::launch_measure_readback(rows_in_order.measure, c->h_meas_dev + idx * 2 * kMaxMeasRows, tiles_y, c->stream));
 		HIP_TRY(hipEventRecord(slot->measured, c->stream));
 		slot->meas_rows = tiles_y;
-		slot->trial_in_flight = trial_now;
+		if ((rc = raise_measure_fence(s, c))) return rc;
 	}
-	// (only streams other than the scene's own ones can be recycled, ctx_for)
-	if (!c->scene_owned) HIP_TRY(hipEventRecord(c->last_launch, c->stream));
+	// what a recycled context waits for (ctx_for) and what a measured launch on another of the scene's streams looks at
+	if (!c->scene_owned || c->stream != s->stream) {
+		HIP_TRY(hipEventRecord(c->last_launch, c->stream));
+		c->launched = true;
+	}
 	return HMRM_OK;
 }
 
@@ -813,6 +768,7 @@ int run_update_heights(hmrm_scene *s) {
 	HIP_TRY(hmrm::launch_prepare_heights(s->d_rgb, s->d_thr, n, s->params.lum_r, s->params.lum_g,
 	                                     s->params.lum_b, s->params.min_height, s->params.max_height,
 	                                     false, s->d_maxkey, s->stream));
+	HIP_TRY(hmrm::launch_thr_to_float(s->d_thr, s->d_thr32, n, s->stream)); // (float)thr, round to nearest
 	// window-maximum pyramid for the exact-leap traversal (render_fast.hip)
 	HIP_TRY(hmrm::launch_build_mip0(s->d_thr, s->map_w, s->map_h, s->plane(s->d_mipbuf, 0), s->mip_w[0], s->mip_h[0],
 	                                s->mip_row, s->stream));
@@ -820,13 +776,10 @@ int run_update_heights(hmrm_scene *s) {
 		HIP_TRY(hmrm::launch_build_mip_up(s->plane(s->d_mipbuf, l - 1), s->mip_w[l - 1], s->mip_h[l - 1],
 		                                  s->plane(s->d_mipbuf, l), s->mip_w[l], s->mip_h[l], s->mip_row, l - 1, s->stream));
 	s->bil_valid = false; // rebuilt by the next bilinear frame
-	s->thr32_valid = false;
 	for (StreamCtx *c : s->ctxs)
 		for (FrameSlot &sl : c->slots) sl.valid = false;
 	s->settled.clear();
-	s->last_settled_group = false; // (new heights: new content)
-	s->kernel_probed = false;
-	s->unprobed_frames = 0;
+	s->choice.reset(); // (new heights: new content)
 	++s->probe_epoch;
 	unsigned long long key = 0;
 	HIP_TRY(hipMemcpyAsync(&key, s->d_maxkey, sizeof key, hipMemcpyDeviceToHost, s->stream));
@@ -898,7 +851,8 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 		HIP_TRY(hipEventCreate(&s->ev1));
 		HIP_TRY(hipMalloc((void **)&s->d_rgb, n * 3));
 		HIP_TRY(hipMalloc((void **)&s->d_cmap, n * 4));
-		HIP_TRY(hipMalloc((void **)&s->d_thr, n * sizeof(double)));
+		HIP_TRY(hipMalloc((void **)&s->d_thr, n * (sizeof(double) + sizeof(float)))); // the table, then its float copy
+		s->d_thr32 = reinterpret_cast<float *>(s->d_thr + n);
 		// every plane has level 0's row pitch and a power-of-two plane pitch (DevFrame); the pyramid of the
 		// bilinear mode is allocated by its first frame
 		(void)mip_layout(map_w, map_h, s->mip_w, s->mip_h, &s->mip_row, &s->mip_plane_shift, s->knobs.min_plane_shift);
@@ -964,7 +918,6 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (s->d_rgb) (void)hipFree(s->d_rgb);
 	if (s->d_cmap) (void)hipFree(s->d_cmap);
 	if (s->d_thr) (void)hipFree(s->d_thr);
-	if (s->d_thr32) (void)hipFree(s->d_thr32);
 	if (s->d_mipbuf) (void)hipFree(s->d_mipbuf);
 	if (s->d_mipbuf_bil) (void)hipFree(s->d_mipbuf_bil);
 	if (s->d_maxkey) (void)hipFree(s->d_maxkey);
@@ -972,6 +925,7 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (s->h_stage) (void)hipHostFree(s->h_stage);
 	if (s->h_probe) (void)hipHostFree(s->h_probe);
 	if (s->probe_done) (void)hipEventDestroy(s->probe_done);
+	if (s->measure_fence) (void)hipEventDestroy(s->measure_fence);
 	if (s->d_steps) (void)hipFree(s->d_steps);
 	if (s->d_entry) (void)hipFree(s->d_entry);
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -984,7 +938,7 @@ int hmrm_debug_kernel_choice(const hmrm_scene *s) {
 	if (!s) return fail(HMRM_E_ARG, "NULL argument");
 	std::lock_guard<std::mutex> lk(const_cast<hmrm_scene *>(s)->mu);
 	if (s->knobs.kernel != 0) return s->knobs.kernel; // forced by HMRM_KERNEL: 1 group, 2 simple
-	return s->last_settled_group ? 1 : 0;
+	return s->choice.use_group ? 1 : 0;
 }
 
 int hmrm_debug_reload_env(hmrm_scene *s) {
@@ -996,18 +950,12 @@ int hmrm_debug_reload_env(hmrm_scene *s) {
 	// changed must not be compared with ones measured after, and an order settled for the old kernel must not be
 	// adopted for the new one.  Every record goes back to "uncalibrated" (pixels never depended on any of this).
 	s->settled.clear();
-	s->last_settled_group = false;
-	s->kernel_probed = false;
-	s->unprobed_frames = 0;
+	s->choice.reset();
 	++s->probe_epoch;
 	for (StreamCtx *c : s->ctxs)
 		for (FrameSlot &sl : c->slots) {
-			if (sl.trial_in_flight >= 0 && sl.measured) HIP_TRY(hipEventSynchronize(sl.measured)); // (its read-back targets the slot's records)
-			sl.trial_in_flight = -1;
-			sl.order_best = -1;
-			sl.n_trials = 1;
-			for (FrameSlot::OrderTrial &t : sl.trials) t = FrameSlot::OrderTrial();
-			sl.uses = 0;
+			if (sl.cal.in_flight >= 0 && sl.measured) HIP_TRY(hipEventSynchronize(sl.measured)); // (its read-back targets the slot's records)
+			sl.cal.reset();
 			if (c->meas_owner == &sl) c->meas_owner = nullptr;
 		}
 	return HMRM_OK;
@@ -1296,6 +1244,10 @@ int hmrm_scene_take_capped(const hmrm_scene *scene, void *hip_stream, uint64_t *
 // ---- asynchronous frames: kernel k+1 runs while frame k crosses PCIe (the reference's counterpart is
 // the blit of the finished framebuffer, SDL_UpdateTexture, hmap.cpp:1082) ----
 int hmrm_render_begin(const hmrm_scene *scene, const hmrm_camera *cam, int32_t *ticket) {
+	return hmrm_render_begin_flags(scene, cam, 0u, ticket);
+}
+
+int hmrm_render_begin_flags(const hmrm_scene *scene, const hmrm_camera *cam, uint32_t flags, int32_t *ticket) {
 	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
 	int rc = check_camera(cam);
 	if (rc) return rc;
@@ -1346,7 +1298,7 @@ int hmrm_render_begin(const hmrm_scene *scene, const hmrm_camera *cam, int32_t *
 	FrameSlot *slot = nullptr;
 	if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
 	hmrm::RowMap rows{0, cam->height, 0, 0, 1, {}, {}, nullptr};
-	if ((rc = launch_frame(s, c, f, slot, rows, r->d_frame, (int64_t)W, nullptr, nullptr, false))) return rc;
+	if ((rc = launch_frame(s, c, f, slot, rows, r->d_frame, (int64_t)W, nullptr, nullptr, false, (flags & HMRM_NO_PROBE) != 0))) return rc;
 	r->ctx = c;
 	HIP_TRY(hipEventRecord(r->kernel_done, c->stream));
 	HIP_TRY(hipStreamWaitEvent(s->copy_stream, r->kernel_done, 0));
@@ -1401,6 +1353,11 @@ void hmrm_render_release(const hmrm_scene *scene, int32_t ticket) {
 
 // ---- frames into device memory through the launch lanes ----
 int hmrm_render_device_begin(const hmrm_scene *scene, const hmrm_camera *cam, void *d_rgba, size_t stride_bytes, int32_t *ticket) {
+	return hmrm_render_device_begin_flags(scene, cam, d_rgba, stride_bytes, 0u, ticket);
+}
+
+int hmrm_render_device_begin_flags(const hmrm_scene *scene, const hmrm_camera *cam, void *d_rgba, size_t stride_bytes, uint32_t flags,
+                                   int32_t *ticket) {
 	hmrm_scene *s = const_cast<hmrm_scene *>(scene);
 	int rc = check_camera(cam);
 	if (rc) return rc;
@@ -1437,7 +1394,7 @@ int hmrm_render_device_begin(const hmrm_scene *scene, const hmrm_camera *cam, vo
 	FrameSlot *slot = nullptr;
 	if ((rc = prepare_frame(s, c, cam, &f, &slot))) return rc;
 	hmrm::RowMap rows{0, cam->height, 0, 0, 1, {}, {}, nullptr};
-	if ((rc = launch_frame(s, c, f, slot, rows, (uint32_t *)d_rgba, (int64_t)(stride_bytes / 4), nullptr, nullptr, false))) return rc;
+	if ((rc = launch_frame(s, c, f, slot, rows, (uint32_t *)d_rgba, (int64_t)(stride_bytes / 4), nullptr, nullptr, false, (flags & HMRM_NO_PROBE) != 0))) return rc;
 	HIP_TRY(hipMemcpyAsync(t->h_capped, c->d_counters + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipEventRecord(t->done, c->stream));
 	t->ctx = c;
@@ -1791,6 +1748,32 @@ int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_
 	if (plane_shift) *plane_shift = shift;
 	if (levels) *levels = hmrm::kMipLevels;
 	return fits ? 1 : 0;
+}
+
+// Test hook (no GPU): the calibration's state machine (launch_order.hpp OrderCalibration / KernelChoice) driven through a
+// sequence of full-frame launches of one camera; the measurement of a launch arrives before the next launch.
+int hmrm_debug_calibrate(const uint64_t *records, int32_t launches, int32_t tile_rows, int32_t rot, int32_t may_probe,
+                         int32_t scene_already_probed, const uint8_t *can_measure, int32_t *trial_used, int32_t *measured,
+                         int32_t *group_kernel, int32_t *n_trials, int32_t *best, int32_t *scene_use_group, int32_t *settled_at_launch) {
+	if (!records || launches <= 0 || tile_rows <= 0 || tile_rows > kMaxMeasRows || rot < 0 || rot >= tile_rows)
+		return fail(HMRM_E_ARG, "hmrm_debug_calibrate: bad argument");
+	hmrm::OrderCalibration cal;
+	hmrm::KernelChoice choice;
+	choice.probed = scene_already_probed != 0;
+	int settled_at = -1;
+	for (int32_t i = 0; i < launches; ++i) {
+		const hmrm::LaunchPlan p = cal.plan(!can_measure || can_measure[i] != 0, choice);
+		if (trial_used) trial_used[i] = p.trial;
+		if (measured) measured[i] = p.measure ? 1 : 0;
+		if (group_kernel) group_kernel[i] = p.use_group ? 1 : 0;
+		if (p.measure && cal.on_measured((const unsigned long long *)records + (size_t)i * 2 * (size_t)tile_rows, tile_rows, rot, may_probe != 0, choice))
+			settled_at = i;
+	}
+	if (n_trials) *n_trials = cal.n_trials;
+	if (best) *best = cal.best;
+	if (scene_use_group) *scene_use_group = choice.use_group ? 1 : 0;
+	if (settled_at_launch) *settled_at_launch = settled_at;
+	return HMRM_OK;
 }
 
 int32_t hmrm_band_local_rows(int32_t height, int32_t band_rows, int32_t band_index, int32_t band_count) {

@@ -179,5 +179,83 @@ void set_tile_order(RowMap *r, int tiles_y, int rot, int n, const int *b, const 
 	}
 }
 
+// ---- the calibration's state machine --------------------------------------------------------------------------------
+bool OrderCalibration::probing() const {
+	for (int k = 1; k < n_trials; ++k)
+		if (trials[k].group) return true;
+	return false;
+}
+
+void OrderCalibration::adopt(const OrderTrial &settled) {
+	trials[1] = settled;
+	trials[1].makespan = 0.0;
+	trials[1].samples = 0;
+	n_trials = 2;
+	best = 1;
+	in_flight = -1;
+}
+
+LaunchPlan OrderCalibration::plan(bool can_measure, const KernelChoice &scene) {
+	++uses;
+	LaunchPlan p;
+	p.trial = best >= 0 ? best : 0;
+	// (the first launch of a camera is never measured: a camera that is rendered once costs nothing)
+	if (best < 0 && in_flight < 0 && uses >= 2 && can_measure)
+		for (int k = 0; k < n_trials; ++k)
+			if (trials[k].samples < kOrderSamples) {
+				p.trial = k;
+				p.measure = true;
+				in_flight = k;
+				break;
+			}
+	// the probing record times both kernels; everybody else renders with the one the scene's probe chose
+	p.use_group = (probing() && (best >= 0 || p.measure)) ? trials[p.trial].group : scene.use_group;
+	return p;
+}
+
+bool OrderCalibration::on_measured(const unsigned long long *rec, int tiles_y, int rot, bool may_probe, KernelChoice &scene) {
+	if (in_flight < 0 || in_flight >= n_trials) return false;
+	OrderTrial &t = trials[in_flight];
+	const double span = std::max(1.0, measured_makespan(rec, tiles_y));
+	t.makespan = t.samples == 0 ? span : std::min(t.makespan, span);
+	++t.samples;
+	if (in_flight == 0 && t.samples == 1) { // the rotation's records: make the candidates
+		OrderTrial &model = trials[n_trials];
+		model = OrderTrial();
+		model.n = plan_order_from_measurement(rec, tiles_y, rot, model.b, model.c);
+		if (model.n > 0) ++n_trials;
+		OrderTrial &split = trials[n_trials];
+		split = OrderTrial();
+		split.n = split_hot_range(rec, tiles_y, rot, 0.45, 0.25, split.b, split.c);
+		bool same = n_trials > 1 && split.n == model.n;
+		for (int k = 0; same && k < 3; ++k) same = split.b[k] == model.b[k] && split.c[k] == model.c[k];
+		if (split.n > 0 && !same) ++n_trials;
+		if (may_probe && !scene.probed) { // the other kernel, under the rotation
+			scene.probed = true;          // (this record's trials hold the probe: one camera per scene)
+			OrderTrial &g = trials[n_trials];
+			g = OrderTrial();
+			g.group = true;
+			++n_trials;
+		}
+	}
+	in_flight = -1;
+	for (int k = 0; k < n_trials; ++k)
+		if (trials[k].samples < kOrderSamples) return false; // more to time
+	// all timed: the shortest stays; another order must beat the rotation by 1 %, the other kernel the best order by 3 %
+	int b = 0;
+	for (int k = 1; k < n_trials; ++k)
+		if (!trials[k].group && trials[k].makespan < 0.99 * trials[0].makespan && trials[k].makespan < trials[b].makespan) b = k;
+	for (int k = 1; k < n_trials; ++k)
+		if (trials[k].group && trials[k].makespan < 0.97 * trials[b].makespan) b = k;
+	best = b;
+	if (probing()) scene.use_group = trials[b].group; // (the probing record decides)
+	return true;
+}
+
+void fold_shadow_probe(KernelChoice &scene, const unsigned long long *leap_rec, const unsigned long long *group_rec, int tiles_y) {
+	const double leap_span = std::max(1.0, measured_makespan(leap_rec, tiles_y));
+	const double group_span = std::max(1.0, measured_makespan(group_rec, tiles_y));
+	scene.use_group = group_span < 0.97 * leap_span;
+}
 
 } // namespace hmrm

@@ -28,4 +28,61 @@ double measured_makespan(const unsigned long long *rec, int tiles_y);
 int plan_order_from_measurement(const unsigned long long *rec, int tiles_y, int rot, int *pb, int *pc);
 int split_hot_range(const unsigned long long *rec, int tiles_y, int rot, double head_frac, double tail_frac, int *pb, int *pc);
 
+// ---- the calibration as a state machine (host logic only: api.cpp owns the HIP events and the record buffers) -----------
+// A camera that is rendered again and again is CALIBRATED: a short list of trial orders -- [0] the rotation, then the
+// model's plan and a generic head / tail / middle split made from the rotation's first records -- each timed by
+// kOrderSamples measured full-frame launches, after which the one with the shortest measured makespan stays (another
+// order must beat the rotation by 1 %).  The last candidate of ONE record per scene is not an order but the OTHER KERNEL:
+// the plain speculative groups without leaps, under the rotation.  On content that admits no jumps (needles on a plateau,
+// white noise: profiles/r04_content.txt) the leap kernel's attempts are pure overhead; the kernel that measures 3 % faster
+// renders the scene from then on.  Same pixels whatever is chosen.
+constexpr int kOrderSamples = 2; // measured launches per trial (one launch's makespan wobbles by a few per cent)
+
+struct OrderTrial {
+	int n = 0, b[3] = {0, 0, 0}, c[3] = {0, 0, 0}; // pieces (n = 0: the plain rotation)
+	bool group = false;                            // the trial runs the plain groups (no leaps), rotation order
+	double makespan = 0.0;                         // measured, ticks: the shorter of its samples; 0 = not yet
+	int samples = 0;
+};
+
+// Which kernel suits a scene's content: probed ONCE per scene and height update, by the first camera that gets calibrated
+// or -- for cameras that never repeat -- by the scene's shadow probe (api.cpp); everybody else renders with the verdict.
+struct KernelChoice {
+	bool probed = false;           // some record's trials hold (or held) the probe, or the shadow probe has been launched
+	bool use_group = false;        // the verdict: the plain groups measured at least 3 % faster
+	unsigned unprobed_frames = 0;  // full frames rendered without any probe (the shadow probe's trigger)
+	void reset() { *this = KernelChoice(); }
+};
+
+struct LaunchPlan {
+	int trial = 0;          // whose order to launch with (index into OrderCalibration::trials)
+	bool measure = false;   // ... as a measured launch, to be reported with on_measured
+	bool use_group = false; // render with the plain groups
+};
+
+struct OrderCalibration { // of one cached camera
+	OrderTrial trials[4];
+	int n_trials = 1;     // known so far (the candidates are made from the rotation's first records)
+	int in_flight = -1;   // the trial whose measured launch has not been reported yet
+	int best = -1;        // settled: index into trials (-1: still calibrating, the rotation is used)
+	unsigned uses = 0;    // full-frame launches planned for this camera
+
+	void reset() { *this = OrderCalibration(); }
+	bool probing() const; // this record's trials hold the scene's kernel probe
+	// Another stream has settled this camera already: adopt its result instead of measuring again.
+	void adopt(const OrderTrial &settled);
+	// The next full-frame launch of this camera.  `can_measure`: the caller has a free set of record buffers and nothing
+	// else of the scene is running that would disturb a measurement.  A plan with `measure` set marks its trial in flight.
+	LaunchPlan plan(bool can_measure, const KernelChoice &scene);
+	// The measured launch in flight has been read back (rec: measured_makespan's layout).  `may_probe`: the scene allows a
+	// kernel probe (production kernel, probe not disabled).  Returns true when the calibration has just settled: trials[best]
+	// is the result (its `group` flag the scene's verdict when this record held the probe -- already stored in `scene`).
+	bool on_measured(const unsigned long long *rec, int tiles_y, int rot, bool may_probe, KernelChoice &scene);
+	// The measured launch in flight is lost (its records were reused, the knobs changed): forget it.
+	void drop_in_flight() { in_flight = -1; }
+};
+
+// The shadow probe's verdict: one frame launched twice, production kernel then plain groups, both measured.
+void fold_shadow_probe(KernelChoice &scene, const unsigned long long *leap_rec, const unsigned long long *group_rec, int tiles_y);
+
 } // namespace hmrm

@@ -22,6 +22,9 @@ NEAREST, BILINEAR, NEAREST_F32 = 0, 1, 2
 _PROJ_NAMES = {"perspective": 1, "spherical": 2, "orthographic": 3}
 
 
+NO_PROBE = 1  # HMRM_NO_PROBE (hmrm.h)
+
+
 class HmrmError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"hmrm error {code}: {msg}")
@@ -106,6 +109,7 @@ def _load():
         "hmrm_scene_take_capped": (C.c_int, [vp, vp, C.POINTER(C.c_uint64)]),
         "hmrm_debug_reload_env": (C.c_int, [vp]),
         "hmrm_debug_kernel_choice": (C.c_int, [vp]),
+        "hmrm_debug_calibrate": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "hmrm_debug_mip_layout": (C.c_int, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "hmrm_band_local_rows": (i32, [i32, i32, i32, i32]),
         "hmrm_render_stats": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(Stats), vp, vp]),
@@ -125,9 +129,11 @@ def _load():
                                               C.c_double, i32, C.c_char_p, C.c_longlong, i32, i32]),
         "hmrm_orbit_frame_owner": (i32, [i32, i32]),
         "hmrm_render_begin": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(i32)]),
+        "hmrm_render_begin_flags": (C.c_int, [vp, C.POINTER(Camera), C.c_uint32, C.POINTER(i32)]),
         "hmrm_render_wait": (C.c_int, [vp, i32, C.POINTER(u8p), C.POINTER(C.c_size_t)]),
         "hmrm_render_release": (None, [vp, i32]),
         "hmrm_render_device_begin": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.POINTER(i32)]),
+        "hmrm_render_device_begin_flags": (C.c_int, [vp, C.POINTER(Camera), vp, C.c_size_t, C.c_uint32, C.POINTER(i32)]),
         "hmrm_render_device_wait": (C.c_int, [vp, i32]),
         "hmrm_config_create": (vp, []),
         "hmrm_config_destroy": (None, [vp]),
@@ -292,11 +298,11 @@ class Scene:
                                            row_begin, row_end, band_rows, band_index, band_count,
                                            C.c_void_p(stream)))
 
-    def render_begin(self, cam: Camera) -> int:
-        """Enqueue a frame (kernel + copy into a pinned frame of the scene's ring) -> ticket."""
+    def render_begin(self, cam: Camera, no_probe: bool = False) -> int:
+        """Enqueue a frame (kernel + copy into a pinned frame of the scene's ring) -> ticket.  no_probe = HMRM_NO_PROBE."""
         self._sync_env()
         t = C.c_int32()
-        _check(lib.hmrm_render_begin(self._h, C.byref(cam), C.byref(t)))
+        _check(lib.hmrm_render_begin_flags(self._h, C.byref(cam), NO_PROBE if no_probe else 0, C.byref(t)))
         return int(t.value)
 
     def render_wait(self, ticket: int, shape, allow_capped=False, copy=True) -> np.ndarray:
@@ -314,11 +320,11 @@ class Scene:
     def render_release(self, ticket: int):
         lib.hmrm_render_release(self._h, ticket)
 
-    def render_device_begin(self, cam: Camera, d_ptr: int, stride_bytes: int) -> int:
-        """Launch a frame into device memory on the next of the scene's launch streams -> ticket."""
+    def render_device_begin(self, cam: Camera, d_ptr: int, stride_bytes: int, no_probe: bool = False) -> int:
+        """Launch a frame into device memory on the next of the scene's launch streams -> ticket.  no_probe = HMRM_NO_PROBE."""
         self._sync_env()
         t = C.c_int32()
-        _check(lib.hmrm_render_device_begin(self._h, C.byref(cam), C.c_void_p(d_ptr), stride_bytes, C.byref(t)))
+        _check(lib.hmrm_render_device_begin_flags(self._h, C.byref(cam), C.c_void_p(d_ptr), stride_bytes, NO_PROBE if no_probe else 0, C.byref(t)))
         return int(t.value)
 
     def render_device_wait(self, ticket: int, allow_capped=False):
@@ -372,6 +378,20 @@ def mip_layout(map_w: int, map_h: int):
     if rc < 0:
         raise HmrmError(rc, last_error())
     return row.value, shift.value, levels.value, bool(rc)
+
+
+def calibrate(records: np.ndarray, rot: int, may_probe=True, scene_already_probed=False, can_measure=None):
+    """hmrm_debug_calibrate: records (launches, tile_rows, 2) uint64 -> dict of the per-launch decisions and the outcome."""
+    rec = np.ascontiguousarray(records, dtype=np.uint64)
+    n, rows = int(rec.shape[0]), int(rec.shape[1])
+    used, meas, grp = (np.zeros(n, dtype=np.int32) for _ in range(3))
+    cm = None if can_measure is None else np.ascontiguousarray(can_measure, dtype=np.uint8)
+    nt, best, verdict, at = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib.hmrm_debug_calibrate(_ptr(rec), n, rows, int(rot), int(bool(may_probe)), int(bool(scene_already_probed)),
+                                    _ptr(cm) if cm is not None else None, _ptr(used), _ptr(meas), _ptr(grp), C.byref(nt), C.byref(best),
+                                    C.byref(verdict), C.byref(at)))
+    return {"settled_at": int(at.value), "trial": used.tolist(), "measured": meas.tolist(), "group": grp.tolist(), "n_trials": int(nt.value),
+            "best": int(best.value), "scene_use_group": bool(verdict.value)}
 
 
 def plan_order(records: np.ndarray, rot: int):

@@ -168,6 +168,12 @@ int hmrm_render_multi(hmrm_scene *const *scenes, int32_t n_scenes, const hmrm_ca
  * tail of one launch (a few long waves) also overlaps the start of the next (small frames: 1080p over a 1024^2 map
  * 0.064 -> 0.042 ms of GPU time per frame, profiles/r04_lanes.txt) -- the caller manages no stream. */
 int  hmrm_render_begin(const hmrm_scene *scene, const hmrm_camera *cam, int32_t *ticket);
+/* Per-frame flags of the ticketed entry points.  HMRM_NO_PROBE: never spend this frame on the scene's one-time kernel probe (a scene
+ * whose cameras never repeat launches its sixth full frame twice, production kernel and plain groups, to measure which suits
+ * its content: a 3-6 ms hiccup on a 4K frame) -- for a caller that counts on every frame's latency.  The probe
+ * then waits for a frame without the flag (or the calibration of a repeated camera). */
+#define HMRM_NO_PROBE 1u
+int  hmrm_render_begin_flags(const hmrm_scene *scene, const hmrm_camera *cam, uint32_t flags, int32_t *ticket);
 int  hmrm_render_wait(const hmrm_scene *scene, int32_t ticket, const uint8_t **rgba, size_t *stride_bytes);
 void hmrm_render_release(const hmrm_scene *scene, int32_t ticket);
 
@@ -178,6 +184,8 @@ void hmrm_render_release(const hmrm_scene *scene, int32_t ticket);
  * free again either way).  Frames in flight must not share memory.  Up to 64 in flight per scene. */
 int  hmrm_render_device_begin(const hmrm_scene *scene, const hmrm_camera *cam, void *d_rgba, size_t stride_bytes,
                               int32_t *ticket);
+int  hmrm_render_device_begin_flags(const hmrm_scene *scene, const hmrm_camera *cam, void *d_rgba, size_t stride_bytes,
+                                    uint32_t flags, int32_t *ticket);
 int  hmrm_render_device_wait(const hmrm_scene *scene, int32_t ticket);
 
 /* The reference's progressive frame driver (hmap.cpp:976-983, `cycle n` key, default 47):
@@ -242,6 +250,18 @@ int hmrm_debug_frame(const hmrm_camera *cam, const hmrm_scene_params *params,
  * grid's row j renders.  Scheduling only -- no order changes a pixel.  Negative = HMRM_E_ARG. */
 int hmrm_debug_plan_order(const uint64_t *records, int32_t tile_rows, int32_t rot, int32_t pieces_begin[3],
                           int32_t pieces_count[3], int32_t *tile_row_of_grid_row);
+
+/* Host-only test hook (no GPU, no reference counterpart): the state machine behind that calibration and the scene's kernel
+ * probe, driven through `launches` full-frame launches of one camera.  records holds, per launch, tile_rows x {start,
+ * longest wave} as above: what a measured launch would report (read only for the launches the machine decides to measure; the
+ * report arrives before the next launch).  can_measure[i] (NULL = always): the caller has free record buffers and the scene's
+ * other streams are idle.  Out, per launch: the trial whose order it uses (0 = the rotation), whether it is measured, whether it
+ * runs the plain-groups kernel; then the number of trials made, the settled one (-1: none yet), the scene's verdict
+ * (1 = plain groups) and the launch whose report settled the calibration (-1: not settled). */
+int hmrm_debug_calibrate(const uint64_t *records, int32_t launches, int32_t tile_rows, int32_t rot, int32_t may_probe,
+                         int32_t scene_already_probed, const uint8_t *can_measure, int32_t *trial_used, int32_t *measured,
+                         int32_t *group_kernel, int32_t *n_trials, int32_t *best, int32_t *scene_use_group,
+                         int32_t *settled_at_launch);
 
 /* Accuracy of the hardware reciprocal v_rcp_f64 on the current device (test hook; no reference counterpart:
  * the reference divides, AABB.cpp:62-63, and the kernel's one-division shortcut through distance() must prove

@@ -94,3 +94,59 @@ def test_bad_arguments_and_missing_records(hmrm):
     assert pieces == [] and perm.tolist() == [(43 + i) % 135 for i in range(135)]
     pieces, perm = hmrm.plan_order(rec[:8], 3)   # too few rows to bother
     assert pieces == [] and sorted(perm.tolist()) == list(range(8))
+
+
+# ---- the calibration's state machine (csrc/launch_order.hpp OrderCalibration / KernelChoice; hmrm_debug_calibrate) ----
+def _launch_records(n_launches, scale):
+    """Per launch the C3-like profile with every wave `scale[i]` times as long (and the dispatch as slow): a launch whose
+    measured makespan is scale[i] times the base one."""
+    rec0, q, start = c3_like_profile()
+    out = np.zeros((n_launches,) + rec0.shape, dtype=np.uint64)
+    for i in range(n_launches):
+        out[i] = records(start * scale[i], q * scale[i])
+    return out
+
+
+def test_calibration_sequence_and_settling(hmrm):
+    rot = 43
+    # launch 0 is never measured; then two samples per trial: rotation, the model's plan, the generic split, the other kernel
+    r = hmrm.calibrate(_launch_records(12, [1.0] * 12), rot)
+    assert r["n_trials"] == 4 and r["measured"] == [0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0]
+    assert r["trial"][:9] == [0, 0, 0, 1, 1, 2, 2, 3, 3] and r["group"][:9] == [0] * 7 + [1, 1]
+    # nothing beat the rotation by 1 % (all makespans equal): the rotation stays, the production kernel stays
+    assert r["settled_at"] == 8 and r["best"] == 0 and not r["scene_use_group"] and r["trial"][9:] == [0, 0, 0] and r["group"][9:] == [0, 0, 0]
+    # trial 1 faster by 0.5 %: not enough; by 2 %: it stays; the shorter of a trial's two samples counts
+    r = hmrm.calibrate(_launch_records(12, [1, 1, 1, 0.995, 0.995, 1, 1, 1, 1, 1, 1, 1]), rot)
+    assert r["best"] == 0
+    r = hmrm.calibrate(_launch_records(12, [1, 1, 1, 1.3, 0.98, 1, 1, 1, 1, 1, 1, 1]), rot)
+    assert r["best"] == 1 and r["trial"][9:] == [1, 1, 1] and r["group"][9:] == [0, 0, 0]
+    # two orders beat the rotation: the shorter one
+    r = hmrm.calibrate(_launch_records(12, [1, 1, 1, 0.98, 0.98, 0.96, 0.97, 1, 1, 1, 1, 1]), rot)
+    assert r["best"] == 2
+    # the other kernel must beat the BEST order by 3 %
+    r = hmrm.calibrate(_launch_records(12, [1, 1, 1, 0.98, 0.98, 1, 1, 0.96, 0.96, 1, 1, 1]), rot)
+    assert r["best"] == 1 and not r["scene_use_group"]
+    r = hmrm.calibrate(_launch_records(12, [1, 1, 1, 0.98, 0.98, 1, 1, 0.94, 0.99, 1, 1, 1]), rot)
+    assert r["best"] == 3 and r["scene_use_group"] and r["group"][9:] == [1, 1, 1] and r["trial"][9:] == [3, 3, 3]
+
+
+def test_calibration_probe_only_once_per_scene_and_only_when_allowed(hmrm):
+    rot = 43
+    for kw in ({"scene_already_probed": True}, {"may_probe": False}):
+        r = hmrm.calibrate(_launch_records(10, [1.0] * 10), rot, **kw)
+        assert r["n_trials"] == 3 and r["settled_at"] == 6 and sum(r["group"]) == 0 and sum(r["measured"]) == 6
+
+
+def test_calibration_waits_while_it_cannot_measure(hmrm):
+    rot = 43
+    can = [1, 0, 0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+    r = hmrm.calibrate(_launch_records(14, [1.0] * 14), rot, can_measure=can)
+    # launches that may not be measured render with the rotation (or the order in force) and the machine does not advance
+    assert r["measured"] == [0, 0, 0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0] and r["trial"][:12] == [0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3]
+    assert r["settled_at"] == 11
+    # a profile the model finds nothing in (every wave equally long: no hot range to reorder) still times the rotation and the probe
+    flat = np.zeros((8, 40, 2), dtype=np.uint64)
+    flat[:, :, 0] = 1000 + np.arange(40)[None, :] * 10
+    flat[:, :, 1] = 500
+    r = hmrm.calibrate(flat, 0)
+    assert r["n_trials"] in (2, 3) and r["settled_at"] >= 4 and r["best"] in (0, r["n_trials"] - 1)

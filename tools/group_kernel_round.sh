@@ -1,14 +1,17 @@
 #!/bin/bash
 # The every-load kernel (HMRM_KERNEL=group: speculative groups, no leaps -- every height load of the reference is executed):
-# group length A/B (-DHMRM_GROUP=n, interleaved builds) and one PMC round (fetch / write / SQ) of the default build on C3.
+# group length / filtered-compare A/B (-DHMRM_GROUP_PLAIN=n, -DHMRM_FILTER32=0; interleaved builds) and one PMC round (fetch / write / SQ) of the default build on C3.
 # Output: gpurun_out/r05_group/.
 set -u
 trap 'bash "$(dirname "$0")/sweep_build.sh" ""' EXIT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r05_group
 mkdir -p "$out"
+# builds to compare (override: BUILDS_STR="flagsA|flagsB|..."); "" = the tree's defaults
+IFS='|' read -r -a BUILDS <<< "${BUILDS_STR:-|-DHMRM_FILTER32=0|-DHMRM_GROUP_PLAIN=8|-DHMRM_GROUP_PLAIN=12}"
+[ ${#BUILDS[@]} -eq 0 ] && BUILDS=("")
 for round in 1 2; do
-  for flags in "" "-DHMRM_GROUP=6" "-DHMRM_GROUP=8" ${EXTRA_BUILDS:-}; do
+  for flags in "${BUILDS[@]}"; do
     bash tools/sweep_build.sh "$flags"
     echo "=== build [$flags] round $round"
     VARIANTS=group timeout -k 10 300 python tools/variants_bench.py ${WLS:-C3 C5 C2} 2>&1 | grep -E "median"
