@@ -63,17 +63,12 @@ constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group of the 
 // what the scene's probe picks on content that admits no jumps, and the kernel SURVEY 8(d)'s byte roofline is defined
 // for).  That kernel waits for its gathers 70 % of the time at 17 % VALU busy (profiles/r05_C3_group_rocprof.txt): more
 // loads in flight per lane pay until the registers cost resident waves -- C3 2.61 ms with 4, 2.37 with 6, 2.57 with 8
-// (profiles/r05_raw/group_len_ab.txt).
+// (profiles/r05_raw/group_len_ab.txt).  Deciding the hit test from a float copy of the table, doubles only where that is
+// unsafe, halves the bytes and changes little: the gathers are bound by lanes, not bytes (r05_experiments.txt section 4).
 #ifndef HMRM_GROUP_PLAIN
 #define HMRM_GROUP_PLAIN 6
 #endif
 constexpr int kGroupPlain = HMRM_GROUP_PLAIN;
-// HMRM_FILTER32 (default 1): the group's hit tests are decided from the float copy of the threshold table where that is
-// provably the reference's decision ("FILTERED COMPARE" in the group block); 0 = every sample loads its double (round 4).
-#ifndef HMRM_FILTER32
-#define HMRM_FILTER32 1
-#endif
-constexpr bool kFilter32 = HMRM_FILTER32 != 0;
 #ifndef HMRM_MIN_LEAP
 #define HMRM_MIN_LEAP 2
 #endif
@@ -179,9 +174,6 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
                                                 int wave, int lane) {
 	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
 	constexpr int U = LEAP ? kGroup : kGroupPlain; // positions per speculative group
-	// (the filtered compare of the group block: in the plain-groups kernel only -- in the production kernel the groups are a
-	// twentieth of the work and the double fall-back's registers cost the general-grid-width instantiations a resident wave)
-	constexpr bool FILTER = SAMP == 0 && kFilter32 && !LEAP;
 	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
 	const float *__restrict__ mip = BILINEAR ? f.mipbuf_bil : f.mipbuf; // the pyramid this sampling mode leaps on
 	const PixelId pid = pixel_of_tile_lane(f, rows, tiles_y, tile_x, gy, wave, lane);
@@ -503,41 +495,11 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 					__builtin_amdgcn_sched_barrier(0);
 				}
 				diag.load_begin(f, 18);
-				bool H[U]; // position j is below its cell's threshold (hmap.cpp:1016), for positions inside the grid
 				if constexpr (BILINEAR) {
 #pragma unroll
 					for (int j = 0; j < U; ++j) {
 						const Bil b = bil_setup(inb[j] ? QX[j] : 0.0, inb[j] ? QY[j] : 0.0, f.map_w, f.map_h);
 						T[j] = bil_mix(b, thr[b.c00], thr[b.c10], thr[b.c01], thr[b.c11]);
-					}
-				} else if constexpr (FILTER) {
-					// FILTERED COMPARE: the test z < thr (a double, hmap.cpp:1013-1016) is decided from the FLOAT copy of the table
-					// wherever that is safe, the double is loaded only where it is not.  F = (float)thr differs from thr by at most
-					// half a float ulp <= |F| 2^-24 (2^-150 where F is subnormal), so with e = |F| 2^-22 + 2^-148:
-					// z - F < -e  =>  z < thr,   z - F > e  =>  z > thr;  in between (z within four float ulps of the threshold: one
-					// sample in ~10^5), for thresholds beyond the float range (F infinite: e infinite, nothing is decided) and for NaN
-					// the group loads the doubles and compares as the reference does.  Same decisions bit for bit, half the bytes
-					// per sample and twice the cells per cache line -- what the plain-groups kernel, which waits for its gathers
-					// 70 % of the time, is short of (profiles/r05_experiments.txt section 4).
-					const float *__restrict__ thrf = reinterpret_cast<const float *>(thr + (size_t)f.map_w * (size_t)f.map_h);
-					float Tf[U];
-#pragma unroll
-					for (int j = 0; j < U; ++j) Tf[j] = *(const float *)((const char *)thrf + (size_t)(cell[j] * 4u));
-					bool unsure = false;
-#pragma unroll
-					for (int j = 0; j < U; ++j) {
-						const double F = (double)Tf[j];
-						const double d = Z[j] - F;
-						const double e = __builtin_fma(__builtin_fabs(F), 0x1p-22, 0x1p-148);
-						H[j] = d < -e;
-						unsure = unsure || (inb[j] && !(__builtin_fabs(d) > e)); // (NaN: unsure)
-					}
-					if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) {
-#pragma unroll
-						for (int j = 0; j < U; ++j) {
-							T[j] = *(const double *)((const char *)thr + (size_t)(cell[j] * 8u)); // hmap.cpp:1013-1014 (+ c0.z)
-							H[j] = Z[j] < T[j];
-						}
 					}
 				} else {
 #pragma unroll
@@ -547,11 +509,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						T[j] = F32 ? (double)*(const float *)((const char *)thr32 + (size_t)(cell[j] * 4u))
 						           : *(const double *)((const char *)thr + (size_t)(cell[j] * 8u)); // hmap.cpp:1013-1014 (+ c0.z)
 				}
-				if constexpr (!FILTER) {
-#pragma unroll
-					for (int j = 0; j < U; ++j) H[j] = Z[j] < T[j];
-					if constexpr (U == 4) diag.load_end(f, 18, T[0], T[1], T[2], T[3]);
-				}
+				if constexpr (U == 4) diag.load_end(f, 18, T[0], T[1], T[2], T[3]);
 				if (budget >= U) {
 					// in order: the first position that leaves the grid (:1006) or hits (:1016) ends the ray
 					int first = U, hit_j = 0;
@@ -559,7 +517,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 					bool hit = false;
 #pragma unroll
 					for (int j = U - 1; j >= 0; --j) { // (selects, last write = earliest position)
-						const bool h = inb[j] && H[j];
+						const bool h = inb[j] && Z[j] < T[j];
 						const bool s = !inb[j] || h;
 						first = s ? j : first;
 						hit = s ? h : hit;
