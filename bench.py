@@ -43,7 +43,7 @@ N = 1: `value` / `ms_per_step` = K frames of the workload's static pose launched
                            every one of those loads (speculative groups, no leaps), same byte roofline;
          rough_terrain     the headline camera over maps built to defeat the traversal (white noise,
                            a 255-spike per 256^2 block, needles on a plateau, a canyon flown at low
-                           altitude): the library as shipped against the plain 4-step groups.
+                           altitude): the library as shipped against the plain speculative groups.
 N > 1: one process per GPU over RCCL, maps replicated.  `value` = frames of BASELINE configs[4]'s
        64-frame orbit ("C5"; `--workload` overrides), frame k on GPU k mod N, K frames per GPU on one
        stream each, no data-path collective, scaling "weak" (`per_rank_ms_per_step`: every rank's own time; `ms_per_step` is
@@ -865,7 +865,7 @@ def main(argv=None):
                     scene_r.close()
         guarded("workloads", blk_workloads)
 
-        # ---- maps built to defeat the traversal: the library as shipped against the plain 4-step groups
+        # ---- maps built to defeat the traversal: the library as shipped against the plain speculative groups
         def blk_rough():
             rough = {}
             n_r = max(3, min(args.steps, 10))
@@ -891,7 +891,7 @@ def main(argv=None):
                 sc.close()
             rough["note"] = ("same camera as the headline (canyon: low and level, down the corridor); kernel_ms = the library as shipped "
                              f"(HIP events, {n_r} launches): the production kernel unless the scene's one-time probe measured the plain "
-                             "groups at least 3 % faster; group_kernel_ms = HMRM_KERNEL=group (speculative 4-step groups, no leaps)")
+                             "groups at least 3 % faster; group_kernel_ms = HMRM_KERNEL=group (speculative groups of 6 positions, no leaps)")
             secondary["rough_terrain"] = rough
         if not args.no_rough and wl.content == "smooth":
             guarded("rough_terrain", blk_rough)
