@@ -69,14 +69,6 @@ constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group of the 
 #define HMRM_GROUP_PLAIN 6
 #endif
 constexpr int kGroupPlain = HMRM_GROUP_PLAIN;
-// HMRM_TILED_THR: the plain-groups kernel reads its thresholds from a copy of the table laid out in 4 x 4-cell tiles (one
-// 128-byte line each; api.cpp builds it behind the float copy).  The rays of an 8 x 8 pixel tile spread over a 2-D patch of
-// cells at a given step, and what bounds that kernel is the number of cache LINES a load instruction's 64 lanes touch
-// (profiles/r05_experiments.txt sections 3-4): rows of 16 cells make 43 lines of a C3 gather, tiles 35.
-#ifndef HMRM_TILED_THR
-#define HMRM_TILED_THR 0
-#endif
-constexpr bool kTiledThr = HMRM_TILED_THR != 0;
 #ifndef HMRM_MIN_LEAP
 #define HMRM_MIN_LEAP 2
 #endif
@@ -182,11 +174,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
                                                 int wave, int lane) {
 	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
 	constexpr int U = LEAP ? kGroup : kGroupPlain; // positions per speculative group
-	constexpr bool TILED = kTiledThr && SAMP == 0 && !LEAP;
 	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
-	// (TILED: the tiled copy sits behind the table and its float copy, on a 128-byte boundary: api.cpp thr_tiled_offset)
-	const unsigned tiles_w = ((unsigned)f.map_w + 3u) >> 2;
-	const char *__restrict__ thr_tiled = TILED ? reinterpret_cast<const char *>(thr) + ((((size_t)f.map_w * (size_t)f.map_h) * 12u + 127u) & ~(size_t)127u) : nullptr;
 	const float *__restrict__ mip = BILINEAR ? f.mipbuf_bil : f.mipbuf; // the pyramid this sampling mode leaps on
 	const PixelId pid = pixel_of_tile_lane(f, rows, tiles_y, tile_x, gy, wave, lane);
 	LoopDiag<STATS> diag; // (empty unless STATS: leap_diag.hpp)
@@ -475,7 +463,6 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 				// U pairs of them cost the general instantiations 12 vector registers (76: 6 waves per SIMD).  The
 				// bilinear mode needs the exact quotients themselves (its weights) and keeps them.
 				double QX[BILINEAR ? U : 1], QY[BILINEAR ? U : 1];
-				int TX[TILED ? U : 1], TY[TILED ? U : 1]; // (the tiled table is addressed by cell coordinates)
 				bool near = false;
 #pragma unroll
 				for (int j = 0; j < U; ++j) {
@@ -493,7 +480,6 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 					}
 					inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;      // hmap.cpp:1006-1011
 					cell[j] = inb[j] ? (unsigned)index_2d(gy, f.map_w, gx) : 0u;
-					if constexpr (TILED) { TX[j] = gx; TY[j] = gy; }
 				}
 				if (GWM == 2 && !BILINEAR && near) { // some position is on a cell boundary to within 2^-20: divide for real
 #pragma unroll
@@ -505,7 +491,6 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						const int gy = cvt_i32_sat(-Y[j] / f.grid_width);
 						inb[j] = (unsigned)gx < wlim && (unsigned)gy < hlim;
 						cell[j] = inb[j] ? (unsigned)index_2d(gy, f.map_w, gx) : 0u;
-						if constexpr (TILED) { TX[j] = gx; TY[j] = gy; }
 					}
 					__builtin_amdgcn_sched_barrier(0);
 				}
@@ -520,16 +505,9 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 #pragma unroll
 					// (32-bit byte offsets from the table's base -- api.cpp caps maps at 2^29 cells -- so that the loads can
 					// take the base from scalar registers: no 64-bit address arithmetic per sample)
-					for (int j = 0; j < U; ++j) {
-						if constexpr (TILED) {
-							// cell (gx, gy) of the tiled copy: tile (gx >> 2, gy >> 2) of tw per row, element (gy & 3) * 4 + (gx & 3)
-							const unsigned tidx = inb[j] ? ((((unsigned)TY[j] >> 2) * tiles_w + ((unsigned)TX[j] >> 2)) << 4) + (((unsigned)TY[j] & 3u) << 2) + ((unsigned)TX[j] & 3u) : 0u;
-							T[j] = *(const double *)(thr_tiled + (size_t)tidx * 8u);
-						} else {
-							T[j] = F32 ? (double)*(const float *)((const char *)thr32 + (size_t)(cell[j] * 4u))
-							           : *(const double *)((const char *)thr + (size_t)(cell[j] * 8u)); // hmap.cpp:1013-1014 (+ c0.z)
-						}
-					}
+					for (int j = 0; j < U; ++j)
+						T[j] = F32 ? (double)*(const float *)((const char *)thr32 + (size_t)(cell[j] * 4u))
+						           : *(const double *)((const char *)thr + (size_t)(cell[j] * 8u)); // hmap.cpp:1013-1014 (+ c0.z)
 				}
 				if constexpr (U == 4) diag.load_end(f, 18, T[0], T[1], T[2], T[3]);
 				if (budget >= U) {
@@ -828,20 +806,6 @@ __global__ __launch_bounds__(256) void k_thr_to_float(const double *__restrict__
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)thr[i];
 }
-
-// The tiled copy of the table (HMRM_TILED_THR): cell (x, y) -> tile (x >> 2, y >> 2), element (y & 3) * 4 + (x & 3).
-__global__ __launch_bounds__(256) void k_tile_thr(const double *__restrict__ thr, int w, int h, double *__restrict__ dst) {
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= (int64_t)w * h) return;
-	const unsigned x = (unsigned)(i % w), y = (unsigned)(i / w), tw = ((unsigned)w + 3u) >> 2;
-	dst[((size_t)(y >> 2) * tw + (x >> 2)) * 16u + ((y & 3u) << 2) + (x & 3u)] = thr[i];
-}
-hipError_t launch_tile_thr(const double *d_thr, int w, int h, double *d_dst, hipStream_t stream) {
-	const int64_t n = (int64_t)w * h;
-	hipLaunchKernelGGL(k_tile_thr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_thr, w, h, d_dst);
-	return hipGetLastError();
-}
-bool render_uses_tiled_thr() { return kTiledThr; }
 
 hipError_t launch_thr_to_float(const double *d_thr, float *d_thr32, int64_t n, hipStream_t stream) {
 	int64_t blocks = (n + 255) / 256;
