@@ -600,23 +600,33 @@ def main(argv=None):
                 st_ = pipes[tag]
 
                 def step():
-                    pipe, pending = st_["pipe"], st_["pending"]
-                    if len(pending) == pipe.depth:
-                        j = pending.pop(0)
-                        f = pipe.collect(j)
-                        if f is not None:
-                            st_["last"] = f
-                    pipe.submit(st_["k"], render_chunk)
-                    pending.append(st_["k"])
-                    st_["k"] += 1
+                    # (this leg has never run over RCCL with more than one rank -- no multi-GPU box in rounds 1-5: an error in it
+                    # is recorded in the leg and must not take the rest of the line down)
+                    if st_.get("error"):
+                        return
+                    try:
+                        pipe, pending = st_["pipe"], st_["pending"]
+                        if len(pending) == pipe.depth:
+                            j = pending.pop(0)
+                            f = pipe.collect(j)
+                            if f is not None:
+                                st_["last"] = f
+                        pipe.submit(st_["k"], render_chunk)
+                        pending.append(st_["k"])
+                        st_["k"] += 1
+                    except Exception as e:  # noqa: BLE001
+                        st_["error"] = f"{type(e).__name__}: {e}"
                 return step
 
             def pipe_drain(tag):
                 st_ = pipes[tag]
-                for j in st_["pending"]:
-                    f = st_["pipe"].collect(j)
-                    if f is not None:
-                        st_["last"] = f
+                try:
+                    for j in st_["pending"]:
+                        f = st_["pipe"].collect(j)
+                        if f is not None:
+                            st_["last"] = f
+                except Exception as e:  # noqa: BLE001
+                    st_["error"] = st_.get("error") or f"{type(e).__name__}: {e}"
                 st_["pending"] = []
             for tag, rotate in (("pipelined_to_rank0", False), ("pipelined_rotating_root", True)):
                 pipes[tag] = {"pipe": make_pipe(rotate), "pending": [], "k": 0, "last": None}
@@ -631,6 +641,8 @@ def main(argv=None):
                     pipe_drain(name)
                 legs[name] = {"ms_per_frame": dt4 * 1e3 / n_frames, "value": steps4 * n_frames / dt4}
             for tag in pipes:
+                if pipes[tag].get("error"):
+                    continue
                 legs[tag]["note"] = ("strips.StripPipeline: 2 frames in flight (double-buffered strips, gather on its own stream); "
                                      "throughput of a SEQUENCE of frames, each still rendered by all ranks" +
                                      ("; frame k is gathered to rank k mod N" if tag.endswith("root") else ""))
@@ -640,7 +652,9 @@ def main(argv=None):
                 if the_rank == 0:
                     ok = ok and np.array_equal(result["frame4"].cpu().numpy(), fb4)
                 for tag in pipes:  # (every rank that was a root of some frame checks the last one it received)
-                    if pipes[tag]["last"] is not None:
+                    if pipes[tag].get("error"):
+                        legs[tag] = {"error": pipes[tag]["error"]}
+                    elif pipes[tag]["last"] is not None:
                         ok = ok and np.array_equal(pipes[tag]["last"].cpu().numpy(), fb4)
                     elif the_rank == 0:
                         ok = False
@@ -655,6 +669,8 @@ def main(argv=None):
             legs_1["gather_to_rank0_over_rccl"]["note"] = "one GPU: no gather, the strip is the frame (reassembly only)"
             block["one_gpu_same_run"] = legs_1
             for name, leg in legs_n.items():
+                if "ms_per_frame" not in leg or "ms_per_frame" not in legs_1.get(name, {}):
+                    continue
                 leg["speedup_vs_one_gpu"] = legs_1[name]["ms_per_frame"] / leg["ms_per_frame"]
                 leg["efficiency"] = leg["speedup_vs_one_gpu"] / world
         block.update(legs_n)
