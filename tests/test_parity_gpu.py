@@ -1236,6 +1236,17 @@ def test_deep_fuzz_slice(gpu, script, args):
     print(tail.strip().splitlines()[-1])  # (visible with -rP / in the junit output: how far the slice got)
 
 
+def test_renders_repeat_bit_for_bit(gpu):
+    """A time-boxed slice of tests/stress_repeat.py: thousands of small random scenes created, rendered seven times each with the
+    instrumented and the plain kernel, and destroyed; every render must equal its scene's first one bit for bit (frames, per-ray
+    step counts, distance() bits).  Looks for races -- copies, tables, stale buffers --, not for arithmetic (builder run, round 5:
+    79 976 scenes, 959 712 renders, none differed)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "stress_repeat.py"), "6000000", "15", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "nondeterministic 0" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_rcp_f64_accuracy_bound(gpu):
     """v_rcp_f64 on THIS device, measured: slab_classify's margins (device_common.hpp kRcpRelErr = 2^-24,
     kSlabMargin = 16x that) hold only while the hardware reciprocal stays within that relative error.  The leading
