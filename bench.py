@@ -299,7 +299,7 @@ def cpu_baseline(hmrm, wl, rgb, cmap, params, cam, target_s=15.0, reps=3):
 
 def workload_text(wl):
     return (f"{wl.name}: {wl.map_size}x{wl.map_size} heightmap, {wl.width}x{wl.height}, {PROJ_NAMES[wl.projection - 1]} "
-            f"hfov {wl.hfov_deg:g}, step_dist {wl.step_dist:g}, grid_width {wl.grid_width:g}"
+            f"hfov {wl.hfov_deg:g}, step_dist {wl.step_dist:g}" + (" cells" if wl.grid_width != 1.0 else "") + f", grid_width {wl.grid_width:g}"
             + ("" if wl.content == "smooth" else f", {wl.content} map"))
 
 
