@@ -602,6 +602,36 @@ int launch_kernel(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const hm
 	return HMRM_OK;
 }
 
+// Behind every launch on a stream other than the scene's own: the event a recycled context waits for (ctx_for) and a measured
+// launch on another of the scene's streams looks at (others_idle).
+int note_launch(hmrm_scene *s, StreamCtx *c) {
+	if (c->scene_owned && c->stream == s->stream) return HMRM_OK;
+	HIP_TRY(hipEventRecord(c->last_launch, c->stream));
+	c->launched = true;
+	return HMRM_OK;
+}
+
+// The kernel launch -- bracketed, when it is a measured one, by the set-up of the records in front of it and their read-back,
+// the record's event and the scene's fence behind it.
+int launch_maybe_measured(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot *slot, hmrm::RowMap &rows_in_order, int tiles_y,
+                          bool measure_now, uint32_t *d_out, int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats, bool use_group) {
+	if (measure_now) {
+		const int rc_m = ensure_meas(c);
+		if (rc_m) return rc_m;
+		if (!slot->measured) HIP_TRY(hipEventCreateWithFlags(&slot->measured, hipEventDisableTiming));
+		rows_in_order.measure = c->d_meas;
+		HIP_TRY(hmrm::launch_measure_init(rows_in_order.measure, tiles_y, c->stream));
+	}
+	const int rc_k = launch_kernel(s, c, f, rows_in_order, d_out, out_stride_px, d_steps, d_entry, stats, use_group);
+	if (rc_k || !measure_now) return rc_k;
+	const size_t idx = (size_t)(slot - c->slots);
+	HIP_TRY(hmrm::launch_measure_readback(rows_in_order.measure, c->h_meas_dev + idx * 2 * kMaxMeasRows, tiles_y, c->stream));
+	HIP_TRY(hipEventRecord(slot->measured, c->stream));
+	slot->meas_rows = tiles_y;
+	c->meas_owner = slot;
+	return raise_measure_fence(s, c);
+}
+
 // One frame (or row strip) on the context's stream.  Kernel variant: "leap" (default; speculative
 // groups + exact leaps), "group" (speculative groups only), "simple" (the literal
 // one-step-at-a-time loop, kept for A/B runs and as an in-library cross-check).  All produce
@@ -639,31 +669,18 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 		if (!measure_now && may_probe && !no_probe && quiet && !s->choice.probed && !s->probe_pending && slot->cal.in_flight < 0 &&
 		    ++s->choice.unprobed_frames >= (unsigned)kProbeAfterFrames) {
 			hmrm::set_tile_order(&rows_in_order, tiles_y, rot, order.n, order.b, order.c);
-			return launch_shadow_probe(s, c, f, rows_in_order, tiles_y, d_out, out_stride_px);
+			if ((rc = launch_shadow_probe(s, c, f, rows_in_order, tiles_y, d_out, out_stride_px))) return rc;
+			return note_launch(s, c);
 		}
 	}
 	hmrm::set_tile_order(&rows_in_order, tiles_y, rot, order.n, order.b, order.c);
-	if (measure_now) {
-		if ((rc = ensure_meas(c))) return rc;
-		if (!slot->measured) HIP_TRY(hipEventCreateWithFlags(&slot->measured, hipEventDisableTiming));
-		rows_in_order.measure = c->d_meas;
-		c->meas_owner = slot;
-		HIP_TRY(hmrm::launch_measure_init(rows_in_order.measure, tiles_y, c->stream));
+	// (a measured launch that cannot be issued or reported must not stay "in flight" in the record: nothing would ever
+	// report it, and the record's next reuse would wait for an event that was never recorded)
+	if ((rc = launch_maybe_measured(s, c, f, slot, rows_in_order, tiles_y, measure_now, d_out, out_stride_px, d_steps, d_entry, stats, use_group))) {
+		if (measure_now) slot->cal.drop_in_flight();
+		return rc;
 	}
-	if ((rc = launch_kernel(s, c, f, rows_in_order, d_out, out_stride_px, d_steps, d_entry, stats, use_group))) return rc;
-	if (measure_now) {
-		const size_t idx = (size_t)(slot - c->slots);
-		HIP_TRY(hmrm::launch_measure_readback(rows_in_order.measure, c->h_meas_dev + idx * 2 * kMaxMeasRows, tiles_y, c->stream));
-		HIP_TRY(hipEventRecord(slot->measured, c->stream));
-		slot->meas_rows = tiles_y;
-		if ((rc = raise_measure_fence(s, c))) return rc;
-	}
-	// what a recycled context waits for (ctx_for) and what a measured launch on another of the scene's streams looks at
-	if (!c->scene_owned || c->stream != s->stream) {
-		HIP_TRY(hipEventRecord(c->last_launch, c->stream));
-		c->launched = true;
-	}
-	return HMRM_OK;
+	return note_launch(s, c);
 }
 
 // Pyramid layout of a map (DevFrame): windows per level, the common row pitch (level 0's) and the log2 of the
