@@ -901,6 +901,38 @@ def test_one_frame_over_several_scenes(gpu, oracle):
         sc.close()
 
 
+def test_strip_pipeline_renders_whole_frames_on_the_gpu(gpu, oracle):
+    """strips.StripPipeline with the HIP renderer behind it, one rank: a sequence of orbit frames, each rendered
+    in `chunks` interleaved band sets into double-buffered device strips (hmrm_render_rows_device in cyclic-band mode with
+    band_count = chunks) and reassembled, equals the oracle's frame for its camera -- two frames in flight, buffers reused."""
+    import torch
+    strips = importlib.import_module("heightmap-ray-marcher_amd.strips")
+    rgb, cmap = scenes.small_maps(96, 80, 53)
+    params = gpu.SceneParams.make(0.0, 9.0, grid_width=1.0)
+    heights = oracle.update_heightmap(rgb, params)
+    scene = gpu.Scene(rgb, cmap, params)
+    base = gpu.Camera.make(width=150, height=101, projection=1, hfov=gpu.degrees_to_rads(80), hang=0.0, vang=gpu.degrees_to_rads(114),
+                           pos=(-30.0, 30.0, 40.0), step_dist=0.25, bg=(4, 5, 6))
+    cams = [gpu.orbit_camera(base, 48.0, -40.0, 90.0, gpu.degrees_to_rads(-45.0), k, 6) for k in range(6)]
+    want = [oracle.render(oracle.make_cfg(c, params, 96, 80), heights, cmap)[0] for c in cams]
+    stream = torch.cuda.current_stream().cuda_stream
+    for chunks, depth in ((1, 2), (3, 2), (2, 3)):
+        plan = strips.BandPlan(height=base.height, width=base.width, band_rows=16, world=1)
+        pipe = strips.StripPipeline(plan, 0, None, torch, "cuda", depth=depth, chunks=chunks)
+
+        def render_rows_of(k):
+            def render_rows(chunk_t, band_rows, band_index, band_count):
+                chunk_t.zero_()
+                scene.render_rows_device(cams[k], chunk_t.data_ptr(), base.width * 4, band_rows=band_rows, band_index=band_index,
+                                         band_count=band_count, stream=stream)
+            return render_rows
+        got = {}
+        pipe.run(range(6), render_rows_of, on_frame=lambda k, f: got.__setitem__(k, f.cpu().numpy()))
+        for k in range(6):
+            assert np.array_equal(got[k], want[k]), (chunks, depth, k)
+    scene.close()
+
+
 def test_two_streams_two_spherical_cameras(gpu, oracle):
     """hmrm_render_rows_device from two HIP streams with two different spherical cameras, alternating
     without a host sync in between: each stream has its own tables / counters (api.cpp StreamCtx), so
