@@ -334,6 +334,38 @@ def test_shadow_probe_for_cameras_that_never_repeat(gpu, oracle):
         scene.close()
 
 
+def test_no_probe_flag_keeps_a_frame_from_being_launched_twice(gpu, oracle):
+    """HMRM_NO_PROBE (hmrm_render_device_begin_flags): a caller that counts on every frame's latency keeps the scene's
+    shadow probe -- one frame launched twice, production kernel and plain groups -- off its frames.  On a map where the probe, once
+    it runs, picks the plain groups (needles) the kernel choice stays "production" through twenty never-repeating flagged frames
+    and changes only after unflagged ones; every frame is the oracle's either way."""
+    import torch
+    wl = gpu.synth.content_workload("C2", "needles")
+    rgb, cmap = wl.maps()
+    params = wl.scene_params()
+    heights = oracle.update_heightmap(rgb, params)
+    scene = gpu.Scene(rgb, cmap, params)
+    out = torch.zeros((360, 640, 4), dtype=torch.uint8, device="cuda")
+
+    def frame(k, no_probe):
+        cam = wl.camera(k, 97)
+        cam.width, cam.height = 640, 360
+        t = scene.render_device_begin(cam, out.data_ptr(), 640 * 4, no_probe=no_probe)
+        scene.render_device_wait(t)
+        return cam
+    for k in range(20):
+        cam = frame(k, True)
+        assert scene.kernel_choice() == 0, k
+    ofb, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap)
+    assert np.array_equal(out.cpu().numpy(), ofb)
+    for k in range(20, 40):
+        cam = frame(k, False)
+    ofb, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap)
+    assert np.array_equal(out.cpu().numpy(), ofb)
+    print("needles, unflagged frames: the shadow probe chose", ("the production kernel", "the plain groups")[scene.kernel_choice()])
+    scene.close()
+
+
 def test_step_cap_is_reported_not_silent(gpu, oracle):
     """A vertical upward ray over a non-hitting cell never leaves the reference's while(true)
     (hmap.cpp:1000-1038).  The kernel stops at the cap, shades a miss and says so."""
