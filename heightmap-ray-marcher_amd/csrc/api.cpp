@@ -661,13 +661,14 @@ int launch_frame(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, FrameSlot
 	bool measure_now = false;
 	if (eligible) {
 		poll_measured(s, c, slot, tiles_y, rot);
-		const bool quiet = c->meas_owner == nullptr && !c->probe_in_flight && others_idle(s, c);
+		// (whether a measurement may run is only looked up -- event queries on the scene's other streams -- while one is wanted)
+		const bool probe_open = may_probe && !no_probe && !s->choice.probed && !s->probe_pending;
+		const bool quiet = (slot->cal.wants_measure() || probe_open) && c->meas_owner == nullptr && !c->probe_in_flight && others_idle(s, c);
 		const hmrm::LaunchPlan p = slot->cal.plan(quiet, s->choice);
 		order = slot->cal.trials[p.trial];
 		use_group = p.use_group;
 		measure_now = p.measure;
-		if (!measure_now && may_probe && !no_probe && quiet && !s->choice.probed && !s->probe_pending && slot->cal.in_flight < 0 &&
-		    ++s->choice.unprobed_frames >= (unsigned)kProbeAfterFrames) {
+		if (!measure_now && probe_open && quiet && slot->cal.in_flight < 0 && ++s->choice.unprobed_frames >= (unsigned)kProbeAfterFrames) {
 			hmrm::set_tile_order(&rows_in_order, tiles_y, rot, order.n, order.b, order.c);
 			if ((rc = launch_shadow_probe(s, c, f, rows_in_order, tiles_y, d_out, out_stride_px))) return rc;
 			return note_launch(s, c);

@@ -186,6 +186,13 @@ bool OrderCalibration::probing() const {
 	return false;
 }
 
+bool OrderCalibration::wants_measure() const {
+	if (best >= 0 || in_flight >= 0 || uses + 1 < 2) return false;
+	for (int k = 0; k < n_trials; ++k)
+		if (trials[k].samples < kOrderSamples) return true;
+	return false;
+}
+
 void OrderCalibration::adopt(const OrderTrial &settled) {
 	trials[1] = settled;
 	trials[1].makespan = 0.0;

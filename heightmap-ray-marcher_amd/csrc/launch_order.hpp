@@ -69,6 +69,9 @@ struct OrderCalibration { // of one cached camera
 
 	void reset() { *this = OrderCalibration(); }
 	bool probing() const; // this record's trials hold the scene's kernel probe
+	// Would the next plan() ask for a measured launch if it may?  (So that the caller only looks whether it may -- event
+	// queries on the scene's other streams -- while a calibration is still going on.)
+	bool wants_measure() const;
 	// Another stream has settled this camera already: adopt its result instead of measuring again.
 	void adopt(const OrderTrial &settled);
 	// The next full-frame launch of this camera.  `can_measure`: the caller has a free set of record buffers and nothing
