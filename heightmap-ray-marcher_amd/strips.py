@@ -213,7 +213,12 @@ class StripPipeline:
         _, root = self._drain_slot(slot)
         if self.rank != root:
             return None
-        return reassemble_torch(self.vplan, self.blocks[slot])
+        frame = reassemble_torch(self.vplan, self.blocks[slot])
+        # The slot's block is written again by frame k + depth: the frame handed out must not be a view of it.  (With one band
+        # per virtual rank the reassembly's permute is the identity and its reshape a view, not a copy.)
+        if frame.untyped_storage().data_ptr() == self.blocks[slot].untyped_storage().data_ptr():
+            frame = frame.clone()
+        return frame
 
     def run(self, frames, render_rows_of, on_frame=None):
         """frames: iterable of frame indices; render_rows_of(k) -> the render_rows callable of frame k.  Keeps `depth`

@@ -216,12 +216,13 @@ def _pipeline_worker(rank, world, port, height, band_rows, depth, chunks, rotate
         return render_rows
 
     got = {}
-    pipe.run(range(frames), render_rows_of, on_frame=lambda k, f: got.__setitem__(k, None if f is None else f.numpy().copy()))
+    # (the frames are kept as handed out, not copied: a frame must stay what it was while later frames reuse the pipeline's buffers)
+    pipe.run(range(frames), render_rows_of, on_frame=lambda k, f: got.__setitem__(k, f))
     ok = True
     for k in range(frames):
         root = (k % world) if rotate else 0
         if rank == root:
-            ok = ok and got[k] is not None and np.array_equal(got[k], _pattern_frame(k, height, width))
+            ok = ok and got[k] is not None and np.array_equal(got[k].numpy(), _pattern_frame(k, height, width))
         else:
             ok = ok and got[k] is None
     # the double buffer's order: frame k + depth is rendered only after frame k has been drained, and with depth > 1 frame
@@ -243,7 +244,8 @@ def _pipeline_worker(rank, world, port, height, band_rows, depth, chunks, rotate
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("height,band_rows,depth,chunks,rotate", [(47, 8, 2, 1, False), (64, 4, 2, 3, True), (33, 16, 3, 2, True), (40, 8, 1, 2, False)])
+@pytest.mark.parametrize("height,band_rows,depth,chunks,rotate", [(47, 8, 2, 1, False), (64, 4, 2, 3, True), (33, 16, 3, 2, True), (40, 8, 1, 2, False),
+                                                                  (60, 16, 2, 2, True)])  # (the last: one band per virtual rank)
 def test_strip_pipeline_world2_gloo(tmp_path, height, band_rows, depth, chunks, rotate):
     """StripPipeline over two gloo ranks: every frame arrives whole on its root (rank 0, or k mod world with a rotating
     root), no buffer is reused before its gather is done, and the next frame is rendered while the previous one's strips
