@@ -35,6 +35,18 @@ def test_gpus_2_without_torchrun_launches_two_ranks_and_relays_one_json_line():
     assert line["scaling"] == "weak" and line["ms_per_step"] > 0
 
 
+def test_four_ranks_dry_launch_incl_the_pipelined_strips():
+    """The rank count the driver uses between 2 and 8.  With 4 ranks and 2 band sets per frame the dry launch's 100-row frame has
+    ONE band per virtual rank -- the case in which StripPipeline's reassembly is a view of the block it gathers into, and a frame
+    handed out used to be overwritten by the frame two later (found by this rehearsal in round 5)."""
+    p = _run("--gpus", "4", "--dry-launch", "--steps", "3", "--warmup", "1")
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["rccl_ranks"]["world_size"] == 4 and line["frames_rendered_by_all_ranks"] == 12
+
+
 def test_under_torchrun_the_same_file_is_a_rank():
     """What the driver does for N > 1: python -m torch.distributed.run ... bench.py --gpus N."""
     import socket
