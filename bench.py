@@ -957,6 +957,7 @@ def main(argv=None):
         pmc, prov = _pmc_from_profiles(wl.name, hmrm.kernel_src_sha())
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         valu = (pmc or {}).get("valu") or {}
+        cnt = (pmc or {}).get("counters_per_frame") or {}
         # VALU pipe-busy cycles per launch, three ways (tools/pmc_summary.py): `isa` = SQ_INSTS_VALU x the calibrated
         # pipe cost of the march loop's own instruction mix (tools/isa_cost.py on the compiler's assembly,
         # profiles/r02_valu_calibration.txt) -- the best estimate, and `frac`; `weighted` prices only the classes the
@@ -986,6 +987,13 @@ def main(argv=None):
             "hbm": {"achieved": (traffic / kernel_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None},
             "lane_util": (pmc or {}).get("lane_util"),
+            # what the busy pipe is busy with (utilisation is not useful work): shares of the VALU wave-instructions
+            # by the classes the counters separate, and the fraction with idle lanes taken out
+            "valu_mix": ({k: (cnt.get(c, 0.0) / valu["insts"]) for k, c in (("fp64_add_mul_fma", None), ("int32", "SQ_INSTS_VALU_INT32"),
+                                                                               ("int64", "SQ_INSTS_VALU_INT64"), ("conversions", "SQ_INSTS_VALU_CVT"),
+                                                                               ("fp64_rcp_sqrt", "SQ_INSTS_VALU_TRANS_F64")) if c}
+                         | {"fp64_add_mul_fma": valu.get("f64_add_mul_fma", 0.0) / valu["insts"]}) if valu.get("insts") else None,
+            "frac_lane_weighted": (frac * pmc["lane_util"]) if (frac and (pmc or {}).get("lane_util")) else None,
             "wave_time": (pmc or {}).get("wave_time"),
             "kernel": "k_render_fast", "kernel_ms": kernel_ms,
             "kernel_ray_steps_per_s": frame_steps / kernel_s,
