@@ -138,7 +138,7 @@ def strip_rows_match(plan: BandPlan, rank: int, host_strip, frame) -> bool:
 # asynchronous gather's work handle alone orders things).
 class StripPipeline:
     def __init__(self, plan: BandPlan, rank: int, dist, torch, device, depth: int = 2, chunks: int = 1,
-                 rotate_root: bool = False, render_stream=None, comm_stream=None):
+                 rotate_root: bool = False, render_stream=None, comm_stream=None, keep_log: bool = False):
         assert depth >= 1 and chunks >= 1
         self.plan, self.rank, self.dist, self.torch = plan, rank, dist, torch
         self.depth, self.chunks, self.rotate_root = depth, chunks, rotate_root
@@ -151,7 +151,11 @@ class StripPipeline:
         self.blocks = [torch.zeros((self.vplan.world, rows, plan.width, 4), dtype=torch.uint8, device=device)
                        if (rotate_root or rank == 0) else None for _ in range(depth)]
         self.inflight = [None] * depth  # per slot: (frame index, root, [work handles], event or None)
-        self.log = []                   # (what, frame, chunk): the order things were issued in (tests)
+        self.log = [] if keep_log else None  # (what, frame, chunk): the order things were issued in (tests only: it grows)
+
+    def _note(self, what, k, c):
+        if self.log is not None:
+            self.log.append((what, k, c))
 
     def root_of(self, k: int) -> int:
         return k % self.plan.world if self.rotate_root else 0
@@ -166,7 +170,7 @@ class StripPipeline:
         if ev is not None:
             ev.synchronize()
         self.inflight[slot] = None
-        self.log.append(("drained", k, -1))
+        self._note("drained", k, -1)
         return k, root
 
     def submit(self, k: int, render_rows):
@@ -182,7 +186,7 @@ class StripPipeline:
         for c in range(self.chunks):
             chunk = self.strips[slot][c]
             render_rows(chunk, self.plan.band_rows, self.rank + world * c, self.vplan.world)
-            self.log.append(("rendered", k, c))
+            self._note("rendered", k, c)
             dst = list(self.blocks[slot][c * world:(c + 1) * world].unbind(0)) if self.rank == root else None
             if self.comm_stream is not None:
                 ready = torch.cuda.Event()
@@ -194,7 +198,7 @@ class StripPipeline:
                 works.append(self.dist.gather(chunk, gather_list=dst, dst=root, async_op=True))
             elif dst is not None:
                 dst[0].copy_(chunk)
-            self.log.append(("gather issued", k, c))
+            self._note("gather issued", k, c)
         ev = None
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
