@@ -195,8 +195,8 @@ struct hmrm_scene {
 	uint8_t *d_rgb = nullptr;   // W*H*3  base_heightmap_buf (hmap.cpp:51)
 	uint32_t *d_cmap = nullptr; // W*H    colormap_buf as packed RGBA (hmap.cpp:59)
 	double *d_thr = nullptr;    // W*H    heightmap_buf[i] + min_height
-	float *d_thr32 = nullptr;   // W*H    the same rounded to float, right behind d_thr in the same allocation: the groups' filtered
-	                            //        compare (render_fast.hip) and the "float heights" mode read it; rebuilt with every update
+	float *d_thr32 = nullptr;   // W*H    the same rounded to float, right behind d_thr in the same allocation: the "float heights"
+	                            //        mode reads it; rebuilt with every update (never lazily beside frames in flight)
 	double thr_max = 0.0;
 	double thr_max_bil = 0.0; // whole-map bound of the interpolated thresholds (bilinear mode)
 	bool bil_valid = false;
