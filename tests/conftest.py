@@ -25,14 +25,14 @@ _ensure_built()
 
 # ---- the GPU suite's time budget (the driver gives `pytest -m gpu` 900 s) ----
 # HMRM_SUITE_BUDGET_S (default 420): wall time the whole suite aims to stay inside.  The time-boxed fuzz slices share
-# HMRM_FUZZ_BUDGET_S (default 300) in fixed proportions, and the two heaviest optional cases (a map with a side of
+# HMRM_FUZZ_BUDGET_S (default 270) in fixed proportions, and the two heaviest optional cases (a map with a side of
 # 2^24 cells, a frame 524 325 rows tall) run only while the suite is inside its budget -- skipped with a message
 # otherwise, never silently.  The suite's wall time is written to gpurun_out/gpu_suite_wall.txt at the end.
 import time
 
 _SUITE_T0 = time.time()
 SUITE_BUDGET_S = float(os.environ.get("HMRM_SUITE_BUDGET_S", "420"))
-FUZZ_BUDGET_S = float(os.environ.get("HMRM_FUZZ_BUDGET_S", "300"))
+FUZZ_BUDGET_S = float(os.environ.get("HMRM_FUZZ_BUDGET_S", "270"))
 
 
 def suite_elapsed_s() -> float:

@@ -1269,7 +1269,7 @@ def test_c4_eight_rank_band_emulation_full_size(gpu, oracle):
     scene.close()
 
 
-# The four slices share ONE time budget (conftest.FUZZ_BUDGET_S, env HMRM_FUZZ_BUDGET_S, default 300 s) in the proportions
+# The four slices share ONE time budget (conftest.FUZZ_BUDGET_S, env HMRM_FUZZ_BUDGET_S, default 270 s) in the proportions
 # 140 : 140 : 90 : 50 : 40 (round 3's four fixed slices were 150 / 150 / 100 / 60 s; round 4 added the cell-boundary fuzzer).
 _FUZZ_SHARES = (("deep_fuzz.py", 140, []), ("deep_fuzz_big.py", 140, ["4096"]), ("deep_fuzz_edges.py", 90, []),
                 ("deep_fuzz_binades.py", 50, []), ("deep_fuzz_cells.py", 40, []))
