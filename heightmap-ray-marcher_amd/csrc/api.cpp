@@ -195,7 +195,6 @@ struct hmrm_scene {
 	uint8_t *d_rgb = nullptr;   // W*H*3  base_heightmap_buf (hmap.cpp:51)
 	uint32_t *d_cmap = nullptr; // W*H    colormap_buf as packed RGBA (hmap.cpp:59)
 	double *d_thr = nullptr;    // W*H    heightmap_buf[i] + min_height
-	float *d_m2 = nullptr;      // W*H    2 x 2-cell maxima of d_thr (HMRM_STRIDE builds), behind the float copy
 	float *d_thr32 = nullptr;   // W*H    the same rounded to float, right behind d_thr in the same allocation: the "float heights"
 	                            //        mode reads it; rebuilt with every update (never lazily beside frames in flight)
 	double thr_max = 0.0;
@@ -788,7 +787,6 @@ int run_update_heights(hmrm_scene *s) {
 	                                     s->params.lum_b, s->params.min_height, s->params.max_height,
 	                                     false, s->d_maxkey, s->stream));
 	HIP_TRY(hmrm::launch_thr_to_float(s->d_thr, s->d_thr32, n, s->stream)); // (float)thr, round to nearest
-	if (s->d_m2) HIP_TRY(hmrm::launch_build_m2(s->d_thr, s->map_w, s->map_h, s->d_m2, s->stream));
 	// window-maximum pyramid for the exact-leap traversal (render_fast.hip)
 	HIP_TRY(hmrm::launch_build_mip0(s->d_thr, s->map_w, s->map_h, s->plane(s->d_mipbuf, 0), s->mip_w[0], s->mip_h[0],
 	                                s->mip_row, s->stream));
@@ -871,11 +869,8 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 		HIP_TRY(hipEventCreate(&s->ev1));
 		HIP_TRY(hipMalloc((void **)&s->d_rgb, n * 3));
 		HIP_TRY(hipMalloc((void **)&s->d_cmap, n * 4));
-		// the table, then its float copy, then -- HMRM_STRIDE builds -- the 2 x 2-cell maxima on a 128-byte boundary
-		const size_t m2_off = (n * (sizeof(double) + sizeof(float)) + 127) & ~(size_t)127;
-		HIP_TRY(hipMalloc((void **)&s->d_thr, m2_off + (hmrm::render_uses_stride_groups() ? n * sizeof(float) : 0)));
+		HIP_TRY(hipMalloc((void **)&s->d_thr, n * (sizeof(double) + sizeof(float)))); // the table, then its float copy
 		s->d_thr32 = reinterpret_cast<float *>(s->d_thr + n);
-		s->d_m2 = hmrm::render_uses_stride_groups() ? reinterpret_cast<float *>(reinterpret_cast<char *>(s->d_thr) + m2_off) : nullptr;
 		// every plane has level 0's row pitch and a power-of-two plane pitch (DevFrame); the pyramid of the
 		// bilinear mode is allocated by its first frame
 		(void)mip_layout(map_w, map_h, s->mip_w, s->mip_h, &s->mip_row, &s->mip_plane_shift, s->knobs.min_plane_shift);

@@ -18,7 +18,6 @@ struct LoopDiag<false> {
 	__device__ __forceinline__ void on_landing_refused(const DevFrame &, bool, bool, bool, bool) {}
 	__device__ __forceinline__ void on_attempt_done(const DevFrame &, bool, bool, bool, bool, bool, bool, bool, int, int) {}
 	__device__ __forceinline__ void on_trip(const DevFrame &, bool, bool) {}
-	__device__ __forceinline__ void on_stride(int, int) {}
 	__device__ __forceinline__ void on_bounds(bool, bool) {}
 	__device__ __forceinline__ void on_group() {}
 	__device__ __forceinline__ void load_begin(const DevFrame &, int) {}
@@ -106,11 +105,6 @@ struct LoopDiag<true> {
 		}
 		leaped += ok ? (unsigned)n : 0u;
 		leaps += ok ? 1u : 0u;
-	}
-	// a stride group (HMRM_STRIDE): its steps count as leaped ones
-	__device__ __forceinline__ void on_stride(int nclear, int adv) {
-		leaped += (unsigned)adv;
-		leaps += nclear > 0 ? 1u : 0u;
 	}
 	// modes 12-15: wave-level view of the loop -- who runs which block, with how many useful lanes
 	__device__ __forceinline__ void on_trip(const DevFrame &f, bool leap_enabled, bool skip_group) {

@@ -32,9 +32,6 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
                               bool leap, hipStream_t stream);
 // thr32[i] = (float)thr[i], round to nearest (the "float heights" mode).
 hipError_t launch_thr_to_float(const double *d_thr, float *d_thr32, int64_t n, hipStream_t stream);
-// Stride groups (render_fast.hip HMRM_STRIDE, experiment): whether this build uses them, and the 2 x 2-cell maxima they read.
-bool render_uses_stride_groups();
-hipError_t launch_build_m2(const double *d_thr, int w, int h, float *d_dst, hipStream_t stream);
 // 3x3 maximum filter of the thr table (bounds every bilinear interpolation, render_fast.hip).
 hipError_t launch_dilate3x3(const double *d_thr, int w, int h, double *d_dst, hipStream_t stream);
 // Window-maximum pyramid (see render_fast.hip): level 0 from the thr table, level l+1 from level l.

@@ -69,18 +69,6 @@ constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group of the 
 #define HMRM_GROUP_PLAIN 6
 #endif
 constexpr int kGroupPlain = HMRM_GROUP_PLAIN;
-// HMRM_STRIDE (experiment, default 0): STRIDE GROUPS.  A lane that needs real steps and whose three coordinates are inside
-// their binades for 4 a more steps takes them as four SEGMENTS of a steps each instead of four steps: the five segment end
-// points are exact positions of the reference's sequence (p_0 + j a delta, sums of binade members), consecutive end points
-// are less than one cell apart per axis, so every position of a segment lies in the 2 x 2 cells around its end points' cells;
-// when both end points are inside the grid and the lower of their heights is at or above the 2 x 2-cell maximum of the
-// thresholds there (a table behind the float copy, api.cpp), no position of the segment can hit (hmap.cpp:1016 needs
-// z < threshold) and all of them are inside the grid (their loads were executed by the reference: counted).  The lane moves
-// on to the first end point whose segment is not clear; a lane that cannot move at all takes real steps next time.
-#ifndef HMRM_STRIDE
-#define HMRM_STRIDE 0
-#endif
-constexpr bool kStride = HMRM_STRIDE != 0 && kStepsLeft;
 #ifndef HMRM_MIN_LEAP
 #define HMRM_MIN_LEAP 2
 #endif
@@ -221,16 +209,6 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 			const double sy = f.step_dist * ray.dy;
 			const double sz = f.step_dist * ray.dz;
 			const unsigned wlim = (unsigned)f.map_w, hlim = (unsigned)f.map_h;
-			// (kStride) steps per segment: the largest count that keeps a segment's ends less than a cell apart on both axes;
-			// below 3 a segment is not worth its arithmetic (0 = this ray takes real steps only).  Performance only: the segment
-			// test below checks the cells themselves.
-			int stride_a = 0;
-			bool force_real = false;
-			if (kStride && LEAP && SAMP == 0 && GWM != 2) {
-				const double cps = __builtin_fmax(__builtin_fabs(sx), __builtin_fabs(sy)) * (GWM == 0 ? 1.0 : f.inv_grid_width);
-				const int a0 = cvt_i32_sat(0.998 * __builtin_amdgcn_rcp(cps)); // (cps = 0: +inf -> saturates, capped below)
-				stride_a = a0 >= 3 ? (a0 > 4096 ? 4096 : a0) : 0;
-			}
 			const int budget0 = f.step_cap > 0x7fffffff ? 0x7fffffff : (int)f.step_cap;
 			int budget = budget0; // every step taken or leaped comes off it: steps so far = budget0 - budget
 			// (int)NaN is INT_MIN on the reference's CPU: the first range test fails, the ray misses
@@ -467,67 +445,6 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 				}
 				diag.on_trip(f, LEAP, skip_group);
 				if (skip_group) continue;
-
-				// --------------------------------------------- stride group (experiment)
-				if (kStride && LEAP && SAMP == 0 && GWM != 2) {
-					const int left_min_g = min(ax.left, min(ay.left, az.left));
-					const bool capable = stride_a > 0 && !force_real && left_min_g >= 4 * stride_a && budget > 4 * stride_a + U;
-					if (__builtin_amdgcn_ballot_w64(capable) != 0ull) {
-						if (capable) {
-							const float *__restrict__ m2 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(thr) +
-							                               ((((size_t)f.map_w * (size_t)f.map_h) * 12u + 127u) & ~(size_t)127u));
-							const double da = (double)stride_a;
-							const double Dx = da * ax.delta, Dy = da * ay.delta, Dz = da * az.delta; // (exact: differences of binade members)
-							int GX[5], GY[5];
-							bool IN[5];
-							{
-								double px = x, py = y; // (the heights of the end points are formed again behind the loads: fewer registers across them)
-#pragma unroll
-								for (int j = 0; j < 5; ++j) {
-									bool unused = false;
-									GX[j] = cvt_i32_sat(cell_coord_fast<GWM>(px, f, unused));
-									GY[j] = GWM == 0 ? cvt_i32_sat_neg(py) : cvt_i32_sat(cell_coord_fast<GWM>(-py, f, unused));
-									IN[j] = (unsigned)GX[j] < wlim && (unsigned)GY[j] < hlim;
-									px = px + Dx;
-									py = py + Dy;
-								}
-							}
-							float M[4];
-							bool seg_ok[4];
-#pragma unroll
-							for (int j = 0; j < 4; ++j) {
-								// (both ends inside the grid, and their cells neighbours: the segment's positions lie in the 2 x 2 block at the
-								// smaller coordinates)
-								seg_ok[j] = IN[j] && IN[j + 1] && (unsigned)(GX[j + 1] - GX[j] + 1) <= 2u && (unsigned)(GY[j + 1] - GY[j] + 1) <= 2u;
-								const unsigned mi = seg_ok[j] ? (unsigned)index_2d(min(GY[j], GY[j + 1]), f.map_w, min(GX[j], GX[j + 1])) : 0u;
-								M[j] = *(const float *)((const char *)m2 + (size_t)(mi * 4u));
-							}
-							int nclear = 0;
-							bool run = true;
-							double z0 = z;
-#pragma unroll
-							for (int j = 0; j < 4; ++j) {
-								const double z1 = z0 + Dz;
-								run = run && seg_ok[j] && __builtin_fmin(z0, z1) >= (double)M[j];
-								nclear += run ? 1 : 0;
-								z0 = z1;
-							}
-							const double fc = (double)nclear;
-							x = x + fc * Dx; // (= PX[nclear], exactly: fc * Dx is a difference of binade members)
-							y = y + fc * Dy;
-							z = z + fc * Dz;
-							const int adv = nclear * stride_a;
-							budget -= adv;
-							ax.left -= adv;
-							ay.left -= adv;
-							az.left -= adv;
-							force_real = nclear == 0;
-							diag.on_stride(nclear, adv);
-						}
-					}
-					if (capable) continue;
-					force_real = false;
-				}
 
 				// --------------------------------------------- speculative group
 				diag.on_group();
@@ -889,26 +806,6 @@ __global__ __launch_bounds__(256) void k_thr_to_float(const double *__restrict__
 	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
 	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)thr[i];
 }
-
-// (kStride) m2[y][x] = the maximum of thr over the cells (x .. x + 1, y .. y + 1), clipped at the map's edge, rounded UP to float.
-__global__ __launch_bounds__(256) void k_build_m2(const double *__restrict__ thr, int w, int h, float *__restrict__ dst) {
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= (int64_t)w * h) return;
-	const int x = (int)(i % w), y = (int)(i / w);
-	double m = -__builtin_huge_val();
-	for (int yy = y; yy <= min(y + 1, h - 1); ++yy)
-		for (int xx = x; xx <= min(x + 1, w - 1); ++xx) {
-			const double v = thr[(int64_t)yy * w + xx];
-			if (v > m) m = v; // (NaN ignored: z < NaN never hits)
-		}
-	dst[i] = round_up_to_float(m);
-}
-hipError_t launch_build_m2(const double *d_thr, int w, int h, float *d_dst, hipStream_t stream) {
-	const int64_t n = (int64_t)w * h;
-	hipLaunchKernelGGL(k_build_m2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_thr, w, h, d_dst);
-	return hipGetLastError();
-}
-bool render_uses_stride_groups() { return kStride; }
 
 hipError_t launch_thr_to_float(const double *d_thr, float *d_thr32, int64_t n, hipStream_t stream) {
 	int64_t blocks = (n + 255) / 256;

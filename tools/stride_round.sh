@@ -1,5 +1,7 @@
 #!/bin/bash
 # Experiment (round 5): stride groups (-DHMRM_STRIDE=1) against the default build, interleaved, under a few level policies
+# Needs the kernel sources of commit f191f00 (the HMRM_STRIDE block was measured slower and taken out again:
+# profiles/r05_experiments.txt §8); on any other tree both builds are the default one.
 # (HMRM_MIN_LEVEL / HMRM_FINEST_PAUSE: where the ray stops looking at windows and takes its steps in groups).
 set -u
 trap 'bash "$(dirname "$0")/sweep_build.sh" ""' EXIT
