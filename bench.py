@@ -892,8 +892,8 @@ def main(argv=None):
                 sc = hmrm.Scene(*wr.maps(), wr.scene_params())
                 cr = wr.camera()
                 fbr, sr, _, _ = sc.render_stats(cr)
-                precondition(sc, cr)  # (includes the scene's one-time kernel probe: leaps or plain groups, whichever measured faster)
-                chosen = ("leaps", "groups", "literal")[sc.kernel_choice()]
+                precondition(sc, cr)  # (includes the scene's one-time kernel probe: pyramid leaps or groups + window records, whichever measured faster)
+                chosen = ("leaps", "groups", "literal", "groups + window records")[sc.kernel_choice()]
                 leap_ms = sc.bench_kernel_ms(cr, n_r)
 
                 def group():
@@ -908,8 +908,10 @@ def main(argv=None):
                                "executed_per_frame": executed(sr)}
                 sc.close()
             rough["note"] = ("same camera as the headline (canyon: low and level, down the corridor); kernel_ms = the library as shipped "
-                             f"(HIP events, {n_r} launches): the production kernel unless the scene's one-time probe measured the plain "
-                             "groups at least 3 % faster; group_kernel_ms = HMRM_KERNEL=group (speculative groups of 6 positions, no leaps)")
+                             f"(HIP events, {n_r} launches): the production kernel unless the scene's one-time probe measured the other kernel -- "
+                             "the speculative groups with leaps over window records (a 16-cell window's maximum without its 8 highest cells, and "
+                             "where those stand) -- at least 3 % faster; group_kernel_ms = HMRM_KERNEL=group (speculative groups of 6 positions, "
+                             "no leaps of any kind: every load of main/hmap.cpp:1013)")
             secondary["rough_terrain"] = rough
         if not args.no_rough and wl.content == "smooth":
             guarded("rough_terrain", blk_rough)

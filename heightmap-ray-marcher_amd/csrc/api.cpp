@@ -54,7 +54,7 @@ namespace {
 // live scene).
 struct Knobs {
 	int64_t step_cap = (int64_t)1 << 26; // HMRM_STEP_CAP
-	int kernel = 0;                      // HMRM_KERNEL: 0 leap, 1 group, 2 simple
+	int kernel = 0;                      // HMRM_KERNEL: 0 leap, 1 group, 2 simple, 3 rec (window records; nearest sampling, else the plain groups)
 	bool tile_order = true;              // HMRM_TILE_ORDER=0 -> row-major launch order
 	int order_mode = 2;                  // HMRM_TILE_ORDER=1 -> plain rotation; 2 (default) -> rotation, then calibrated from measurement
 	int diag_mode = 0;                   // HMRM_DIAG_ITERS (tools)
@@ -76,7 +76,7 @@ Knobs read_knobs() {
 		const long long v = atoll(s);
 		if (v > 0) k.step_cap = v > 0x7fffffffLL ? 0x7fffffffLL : (int64_t)v;
 	}
-	if (const char *s = getenv("HMRM_KERNEL")) k.kernel = strcmp(s, "simple") == 0 ? 2 : (strcmp(s, "group") == 0 ? 1 : 0);
+	if (const char *s = getenv("HMRM_KERNEL")) k.kernel = strcmp(s, "simple") == 0 ? 2 : (strcmp(s, "group") == 0 ? 1 : (strcmp(s, "rec") == 0 ? 3 : 0));
 	if (const char *s = getenv("HMRM_TILE_ORDER")) {
 		k.tile_order = s[0] != '0';
 		if (s[0] == '1' || s[0] == '2') k.order_mode = s[0] - '0';
@@ -202,6 +202,7 @@ struct hmrm_scene {
 	bool bil_valid = false;
 	float *d_mipbuf_bil = nullptr; // the same over the 3x3-dilated table (bilinear quality mode)
 	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/8/../256-cell windows every 2/4/../128 cells
+	hmrm::WindowRecord *d_records = nullptr; // frame.hpp: the 16-cell windows' maxima without their 8 highest cells, and those cells (null: map too tall for the build's grid)
 	int32_t mip_w[hmrm::kMipLevels] = {}, mip_h[hmrm::kMipLevels] = {};
 	int32_t mip_row = 0, mip_plane_shift = 0; // plane layout of both pyramids, see DevFrame
 	size_t mip_floats() const { return (size_t)(hmrm::kMipLevels + 1) << mip_plane_shift; }
@@ -551,11 +552,12 @@ void poll_shadow_probe(hmrm_scene *s) {
 	if (s->probe_epoch_launched != s->probe_epoch) return; // (the heights or the knobs changed meanwhile)
 	hmrm::fold_shadow_probe(s->choice, s->h_probe, s->h_probe + 2 * kMaxMeasRows, s->probe_rows);
 	if (s->knobs.order_verbose)
-		fprintf(stderr, "hmrm probe: production kernel %.1f us, plain groups %.1f us -> %s\n", hmrm::measured_makespan(s->h_probe, s->probe_rows) / 100.0,
-		        hmrm::measured_makespan(s->h_probe + 2 * kMaxMeasRows, s->probe_rows) / 100.0, s->choice.use_group ? "plain groups" : "production kernel");
+		fprintf(stderr, "hmrm probe: production kernel %.1f us, the other kernel %.1f us -> %s\n", hmrm::measured_makespan(s->h_probe, s->probe_rows) / 100.0,
+		        hmrm::measured_makespan(s->h_probe + 2 * kMaxMeasRows, s->probe_rows) / 100.0, s->choice.use_group ? (s->choice.with_records ? "groups + window records" : "plain groups") : "production kernel");
 }
 
-// The shadow probe: this frame twice into the same buffer -- production kernel, then the plain groups; same pixels, the
+// The shadow probe: this frame twice into the same buffer -- production kernel, then the other kernel (launch_kernel: the
+// plain groups, with window records for nearest-sampling frames); same pixels, the
 // second launch's capped rays counted apart -- both measured like a calibration launch.
 int launch_shadow_probe(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const hmrm::RowMap &rows_in_order, int tiles_y,
                         uint32_t *d_out, int64_t out_stride_px) {
@@ -568,10 +570,13 @@ int launch_shadow_probe(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, co
 	if (rc_m) return rc_m;
 	hmrm::RowMap measured = rows_in_order;
 	measured.measure = c->d_meas;
+	const bool records_ok = f.sampling == 0 && s->d_records; // (the other kernel of this frame: launch_kernel)
+	s->choice.with_records = records_ok;
 	for (int pass = 0; pass < 2; ++pass) {
 		HIP_TRY(hmrm::launch_measure_init(measured.measure, tiles_y, c->stream));
 		HIP_TRY(hmrm::launch_render_fast(f, measured, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
-		                                 c->d_counters + (pass ? 8 : 0), nullptr, nullptr, false, pass == 0, c->stream));
+		                                 c->d_counters + (pass ? 8 : 0), nullptr, nullptr, false,
+		                                 pass == 0 ? hmrm::kLeaps : (records_ok ? hmrm::kRecords : hmrm::kPlainGroups), s->d_records, c->stream));
 		HIP_TRY(hmrm::launch_measure_readback(measured.measure, s->h_probe_dev + (size_t)pass * 2 * kMaxMeasRows, tiles_y, c->stream));
 	}
 	HIP_TRY(hipEventRecord(s->probe_done, c->stream));
@@ -585,7 +590,8 @@ int launch_shadow_probe(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, co
 }
 
 // The render kernel itself: the literal loop (HMRM_KERNEL=simple, or a map with a side of 2^24 cells or more -- the production
-// kernel indexes cells and windows with 24-bit multiplies, leap_common.hpp index_2d), else the production kernel or the plain groups.
+// kernel indexes cells and windows with 24-bit multiplies, leap_common.hpp index_2d), else the production kernel or the other one (the plain groups,
+// with leaps over window records where the frame's sampling allows them).
 int launch_kernel(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const hmrm::RowMap &rows_in_order, uint32_t *d_out,
                   int64_t out_stride_px, uint32_t *d_steps, double *d_entry, bool stats, bool use_group) {
 	const bool huge_side = s->map_w >= (1 << 24) || s->map_h >= (1 << 24);
@@ -595,9 +601,18 @@ int launch_kernel(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const hm
 		HIP_TRY(hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters, d_steps,
 		                            d_entry, stats, c->stream));
 	} else {
-		const bool leap = s->knobs.kernel != 1 && !use_group;
+		// The other kernel: the plain groups, with leaps over window records where the sampling allows them (the records bound
+		// the nearest cell's double thresholds).  The probe's verdict holds for the frames that would run what it measured.
+		const bool records_ok = f.sampling == 0 && s->d_records;
+		hmrm::FastKernel k = hmrm::kLeaps;
+		if (s->knobs.kernel == 1) k = hmrm::kPlainGroups;
+		else if (s->knobs.kernel == 3) k = records_ok ? hmrm::kRecords : hmrm::kPlainGroups;
+		else if (use_group && !(s->choice.use_group && s->choice.with_records != records_ok)) {
+			k = records_ok ? hmrm::kRecords : hmrm::kPlainGroups;
+			if (!s->choice.use_group) s->choice.with_records = records_ok; // (a trial of the probe: this is what it measures)
+		}
 		HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
-		                                 c->d_counters, d_steps, d_entry, stats, leap, c->stream));
+		                                 c->d_counters, d_steps, d_entry, stats, k, s->d_records, c->stream));
 	}
 	return HMRM_OK;
 }
@@ -793,6 +808,7 @@ int run_update_heights(hmrm_scene *s) {
 	for (int l = 1; l < hmrm::kMipLevels; ++l)
 		HIP_TRY(hmrm::launch_build_mip_up(s->plane(s->d_mipbuf, l - 1), s->mip_w[l - 1], s->mip_h[l - 1],
 		                                  s->plane(s->d_mipbuf, l), s->mip_w[l], s->mip_h[l], s->mip_row, l - 1, s->stream));
+	if (s->d_records) HIP_TRY(hmrm::launch_build_records(s->d_thr, s->map_w, s->map_h, s->d_records, s->stream));
 	s->bil_valid = false; // rebuilt by the next bilinear frame
 	for (StreamCtx *c : s->ctxs)
 		for (FrameSlot &sl : c->slots) sl.valid = false;
@@ -875,6 +891,8 @@ int hmrm_scene_create(const uint8_t *height_rgb, const uint8_t *color_rgba, int3
 		// bilinear mode is allocated by its first frame
 		(void)mip_layout(map_w, map_h, s->mip_w, s->mip_h, &s->mip_row, &s->mip_plane_shift, s->knobs.min_plane_shift);
 		HIP_TRY(hipMalloc((void **)&s->d_mipbuf, s->mip_floats() * sizeof(float)));
+		if ((map_h + 3) / 4 <= 65535 * 16)
+			HIP_TRY(hipMalloc((void **)&s->d_records, (size_t)hmrm::rec_row(map_w) * (size_t)((map_h + 3) / 4) * sizeof(hmrm::WindowRecord)));
 		HIP_TRY(hipMalloc((void **)&s->d_maxkey, sizeof(unsigned long long)));
 		HIP_TRY(hipMemcpyAsync(s->d_rgb, height_rgb, n * 3, hipMemcpyHostToDevice, s->stream));
 		HIP_TRY(hipMemcpyAsync(s->d_cmap, color_rgba, n * 4, hipMemcpyHostToDevice, s->stream));
@@ -937,6 +955,7 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 	if (s->d_cmap) (void)hipFree(s->d_cmap);
 	if (s->d_thr) (void)hipFree(s->d_thr);
 	if (s->d_mipbuf) (void)hipFree(s->d_mipbuf);
+	if (s->d_records) (void)hipFree(s->d_records);
 	if (s->d_mipbuf_bil) (void)hipFree(s->d_mipbuf_bil);
 	if (s->d_maxkey) (void)hipFree(s->d_maxkey);
 	if (s->d_frame) (void)hipFree(s->d_frame);
@@ -955,8 +974,8 @@ void hmrm_scene_destroy(hmrm_scene *s) {
 int hmrm_debug_kernel_choice(const hmrm_scene *s) {
 	if (!s) return fail(HMRM_E_ARG, "NULL argument");
 	std::lock_guard<std::mutex> lk(const_cast<hmrm_scene *>(s)->mu);
-	if (s->knobs.kernel != 0) return s->knobs.kernel; // forced by HMRM_KERNEL: 1 group, 2 simple
-	return s->choice.use_group ? 1 : 0;
+	if (s->knobs.kernel != 0) return s->knobs.kernel; // forced by HMRM_KERNEL: 1 group, 2 simple, 3 rec
+	return s->choice.use_group ? (s->choice.with_records ? 3 : 1) : 0;
 }
 
 int hmrm_debug_reload_env(hmrm_scene *s) {

@@ -47,7 +47,8 @@ struct DevFrame {
 	// kernel needs no per-level table -- and plane kMipLevels holds one element, the whole-map
 	// bound (thr_max rounded up).
 	const float *mipbuf;
-	const float *mipbuf_bil;     // the same pyramid over the 3x3-dilated table (bilinear quality mode)
+	const float *mipbuf_bil;     // the same pyramid over the 3x3-dilated table (bilinear quality mode); the record kernel
+	                             // (nearest sampling only) finds its WindowRecord table here instead -- see below
 	int32_t mip_row;             // row pitch of every plane (windows per row of level 0)
 	int32_t mip_plane_shift;     // log2 of the plane pitch
 	// Perspective / spherical: every ray starts at cam, so on which side of the origin the box lies per axis
@@ -104,6 +105,27 @@ constexpr int mip_stride_shift(int l) { return kLevelStep * l + (l < kDenseFrom 
 __host__ __device__
 #endif
 inline unsigned mip_index(int ix, int iy, int pitch) { return (unsigned)(iy * pitch + ix); }
+
+// Window records (render_fast.hip, the record kernel): one per window of level kRecLevel (16 x 16 cells, one every 4
+// cells, row pitch rec_row(map_w)).  `max2` is the window's maximum with its kRecCells highest cells left out (rounded up
+// to float like the pyramid, NaN ignored), xs / ys the places of those cells inside the window, one byte each (255: slot
+// not used -- fewer than kRecCells cells stand above max2).  A ray at or above max2 crosses the window without a load if
+// its path misses the recorded cells: maps whose windows all hold a few tall cells (needles on a plateau) defeat a flat
+// maximum, not this.  Performance only: the kernel that uses the records renders the same pixels.
+constexpr int kRecLevel = 2;
+constexpr int kRecCells = 8;
+struct WindowRecord {
+	float max2;
+	uint32_t spare0;
+	uint32_t xs[2], ys[2];
+	uint32_t spare1[2];
+};
+static_assert(sizeof(WindowRecord) == 32, "two 16-byte loads");
+static_assert(kRecLevel >= kDenseFrom && kLevelStep == 1, "the record level's windows: 16 cells, every 4");
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int rec_row(int map_w) { return (map_w + 3) >> 2; }
 
 // Which framebuffer rows a launch covers and where they land in the output.
 struct RowMap {

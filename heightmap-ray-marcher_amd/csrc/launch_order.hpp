@@ -33,7 +33,8 @@ int split_hot_range(const unsigned long long *rec, int tiles_y, int rot, double 
 // model's plan and a generic head / tail / middle split made from the rotation's first records -- each timed by
 // kOrderSamples measured full-frame launches, after which the one with the shortest measured makespan stays (another
 // order must beat the rotation by 1 %).  The last candidate of ONE record per scene is not an order but the OTHER KERNEL:
-// the plain speculative groups without leaps, under the rotation.  On content that admits no jumps (needles on a plateau,
+// the plain speculative groups without pyramid leaps (with leaps over window records where the frame's sampling allows
+// them: api.cpp launch_kernel), under the rotation.  On content that admits no jumps (needles on a plateau,
 // white noise: profiles/r04_content.txt) the leap kernel's attempts are pure overhead; the kernel that measures 3 % faster
 // renders the scene from then on.  Same pixels whatever is chosen.
 constexpr int kOrderSamples = 2; // measured launches per trial (one launch's makespan wobbles by a few per cent)
@@ -49,7 +50,9 @@ struct OrderTrial {
 // or -- for cameras that never repeat -- by the scene's shadow probe (api.cpp); everybody else renders with the verdict.
 struct KernelChoice {
 	bool probed = false;           // some record's trials hold (or held) the probe, or the shadow probe has been launched
-	bool use_group = false;        // the verdict: the plain groups measured at least 3 % faster
+	bool use_group = false;        // the verdict: the other kernel -- the plain groups, or for nearest-sampling frames their
+	                               // extension by window records (frame.hpp WindowRecord) -- measured at least 3 % faster
+	bool with_records = false;     // which of the two the probe's launches ran: the verdict holds for frames that would run the same
 	unsigned unprobed_frames = 0;  // full frames rendered without any probe (the shadow probe's trigger)
 	void reset() { *this = KernelChoice(); }
 };

@@ -23,13 +23,17 @@ hipError_t launch_render(const DevFrame &f, const RowMap &rows, const double *d_
                          unsigned long long *d_counters, uint32_t *d_steps, double *d_entry,
                          bool stats, hipStream_t stream);
 
-// Production kernel (render_fast.hip): speculative step groups, plus exact leaps over
-// empty pyramid blocks when `leap`.  Same outputs as launch_render.
+// Production kernel (render_fast.hip): speculative step groups (kPlainGroups), plus exact leaps over empty pyramid
+// windows (kLeaps), or over windows of the record level that are empty but for a few recorded cells the ray's path
+// misses (kRecords: nearest sampling only, `d_records` from launch_build_records).  Same outputs as launch_render.
 // f.sampling == 2 reads the float copy of the table (d_thr32, launch_thr_to_float) instead of d_thr.
+enum FastKernel { kPlainGroups = 0, kLeaps = 1, kRecords = 2 };
 hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr, const float *d_thr32,
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
-                              bool leap, hipStream_t stream);
+                              FastKernel kernel, const WindowRecord *d_records, hipStream_t stream);
+// The record table of the thr table: rec_row(map_w) x ceil(map_h / 4) WindowRecords.
+hipError_t launch_build_records(const double *d_thr, int map_w, int map_h, WindowRecord *d_dst, hipStream_t stream);
 // thr32[i] = (float)thr[i], round to nearest (the "float heights" mode).
 hipError_t launch_thr_to_float(const double *d_thr, float *d_thr32, int64_t n, hipStream_t stream);
 // 3x3 maximum filter of the thr table (bounds every bilinear interpolation, render_fast.hip).

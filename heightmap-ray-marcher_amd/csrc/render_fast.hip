@@ -167,13 +167,15 @@ __device__ TimelineRec *g_timeline = nullptr;
 // (-1: the grid row does not exist).  k_render_fast calls it with the tile = blockIdx (one tile per workgroup); round 4's
 // persistent-tile experiment (resident waves pulling tiles from queue heads) called it in a loop and was 1.4-1.9 x slower:
 // profiles/r04_experiments.txt section 1, code at commit 80527e9.
-template <int PROJ, bool STATS, int GWM, bool LEAP, int SAMP>
+template <int PROJ, bool STATS, int GWM, int LEAP, int SAMP>
 __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap &rows, const double *__restrict__ thr,
                                                 const uint32_t *__restrict__ cmap, uint32_t *__restrict__ out,
                                                 int64_t out_stride_px, int tiles_y, const StatsOut &st, int tile_x, unsigned gy,
                                                 int wave, int lane) {
 	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
-	constexpr int U = LEAP ? kGroup : kGroupPlain; // positions per speculative group
+	constexpr bool REC = LEAP == 2;                     // leaps over window records instead of the pyramid (frame.hpp WindowRecord)
+	constexpr int U = LEAP == 1 ? kGroup : kGroupPlain; // positions per speculative group
+	static_assert(!REC || SAMP == 0, "records bound the nearest cell's double thresholds only");
 	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
 	const float *__restrict__ mip = BILINEAR ? f.mipbuf_bil : f.mipbuf; // the pyramid this sampling mode leaps on
 	const PixelId pid = pixel_of_tile_lane(f, rows, tiles_y, tile_x, gy, wave, lane);
@@ -227,7 +229,9 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 				for (int l = kMipLevels - 1; l >= 0; l -= (kAdaptive ? 2 : 1)) // windows every 1 << hs cells: at least that much room ahead
 					lev = (l >= f.min_level && lateral <= (double)((win_strides(l) - 1) << mip_stride_shift(l))) ? l : lev;
 			}
+			if (REC) lev = lev == kTopLevel ? kTopLevel : kRecLevel; // (the record kernel knows the whole-map bound and the record level)
 			int cooldown = 0, fails = 0;
+			unsigned trip_no = 0; // (REC)
 			int jumps = 0; // successful jumps so far (kAdaptive)
 			Axis ax, ay, az;
 			ax.key = ay.key = az.key = 0xfffffffeu; // never matches: forces the first refresh
@@ -248,7 +252,10 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 				diag.begin_trip();
 				// ---------------------------------------------------------- leap
 				if (LEAP) {
-					const bool attempt = cooldown == 0;
+					// (REC: after `fails` refusals in a row a ray attempts on every 2^fails-th trip of the WAVE's count -- rays that
+					// back off do so in step, and on a map that admits no leaps the block is issued once in 64 trips)
+					const bool attempt = REC ? (trip_no & ((1u << fails) - 1u)) == 0u : cooldown == 0;
+					++trip_no;
 					cooldown -= attempt ? 0 : 1;
 					if (attempt) {
 						diag.on_attempt();
@@ -305,8 +312,17 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						// need not: a 64-bit offset, one v_lshl_add_u64 where the 32-bit form had a shift.  Measured equal within the
 						// run-to-run spread on C3 / C5 / C2 / C4, profiles/r05_raw/wide_mip_abn.txt; with HMRM_WIDE_MIP 0 -- round 4 --
 						// very oblong maps near the 2^29-cell limit, 16385 x 32766, had to be rendered by the literal loop, 85 x slower.)
-						float mf = HMRM_WIDE_MIP ? mip[(size_t)(inb0 ? widx : 0u)]
+						float mf = HMRM_WIDE_MIP ? mip[(size_t)((REC ? inb0 && top : inb0) ? widx : 0u)]
 						                         : *(const float *)((const char *)mip + (size_t)((inb0 ? widx : 0u) * 4u));
+						uint32_t rec_xs0 = ~0u, rec_xs1 = ~0u, rec_ys0 = ~0u, rec_ys1 = ~0u;
+						if constexpr (REC) { // the window's record: two 16-byte loads of one 32-byte line
+							const WindowRecord *recs = reinterpret_cast<const WindowRecord *>(f.mipbuf_bil);
+							const unsigned ridx = (inb0 && !top) ? (unsigned)index_2d(iy, rec_row(f.map_w), ix) : 0u;
+							const uint4 r0 = *reinterpret_cast<const uint4 *>(recs + ridx);
+							const uint2 r1 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(recs + ridx) + 16);
+							mf = top ? mf : __uint_as_float(r0.x);
+							rec_xs0 = r0.z; rec_xs1 = r0.w; rec_ys0 = r1.x; rec_ys1 = r1.y;
+						}
 						diag.load_end(f, 17, mf);
 						if (kEarlyLoad) refresh_stale();
 						const bool exact = kStepsLeft ? (ax.left | ay.left | az.left) >= 0
@@ -387,6 +403,38 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 							     (kStepsLeft || (axis_landing_ok(ax, xn) && axis_landing_ok(ay, yn) && axis_landing_ok(az, zn)));
 							diag.on_landing_refused(f, can && !ok, inbn,
 							                        (unsigned)(gxn - wx0) < (unsigned)wspan_x && (unsigned)(gyn - wy0) < (unsigned)wspan_y, zn >= m);
+							if constexpr (REC) {
+								// The positions leaped over are x + k delta, k = 0 .. n - 1 (kCross: up to (xm, ym); else up to the landing
+								// point): all ON the segment between the first and the last, inside the window, at heights >= max2.  None
+								// of them may lie in a recorded cell: segment against each cell's box, in cells relative to the window's
+								// corner, float -- values below 32, conversion and product errors below 2^-13 -- with the box grown by
+								// 2^-10 and the line test given 2^-9 of slack: conservative, never wrong.  (Separating axes: the
+								// segment's extent in x, in y, and the line through it against the box's four corners.)
+								const double bxd = kCross ? xm : xn, byd = kCross ? ym : yn;
+								const double qbx = GWM == 0 ? bxd : bxd * f.inv_grid_width, qby = GWM == 0 ? -byd : -byd * f.inv_grid_width;
+								const float pax = (float)(qx2 - (double)wx0), pay = (float)(qy2 - (double)wy0);
+								const float pbx = (float)(qbx - (double)wx0), pby = (float)(qby - (double)wy0);
+								constexpr float grow = 0x1p-10f;
+								const float ddx = pbx - pax, ddy = pby - pay;
+								const float x_lo = __builtin_fminf(pax, pbx) - (1.0f + grow), x_hi = __builtin_fmaxf(pax, pbx) + grow;
+								const float y_lo = __builtin_fminf(pay, pby) - (1.0f + grow), y_hi = __builtin_fmaxf(pay, pby) + grow;
+								const float reach = (0.5f + grow) * (__builtin_fabsf(ddx) + __builtin_fabsf(ddy)) + 0x1p-9f;
+								const float cax = pax - 0.5f, cay = pay - 0.5f; // (cell corner - this = cell centre - start)
+								bool touched = false;
+#pragma unroll
+								for (int k = 0; k < kRecCells; ++k) {
+									const uint32_t wxs = k < 4 ? rec_xs0 : rec_xs1, wys = k < 4 ? rec_ys0 : rec_ys1;
+									const float cx = (float)((wxs >> (8 * (k & 3))) & 0xffu), cy = (float)((wys >> (8 * (k & 3))) & 0xffu);
+									const float ex = cx - cax, ey = cy - cay;
+									const float cross = ex * ddy - ey * ddx;
+									const bool apart = cx > x_hi || cx < x_lo || cy > y_hi || cy < y_lo || __builtin_fabsf(cross) > reach;
+									touched = touched || !apart;
+								}
+								// (the reference truncates: a coordinate in (-1, 0) -- a ray on its way out through the map's low edge --
+								// still names cell 0, which no box says.  Such paths are marched.)
+								const bool floor_is_trunc = __builtin_fmin(qx2, qbx) >= 0.0 && __builtin_fmin(qy2, qby) >= 0.0;
+								ok = ok && (top || (!touched && floor_is_trunc));
+							}
 							x = ok ? xn : x;
 							y = ok ? yn : y;
 							z = ok ? zn : z;
@@ -441,6 +489,13 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 						// another attempt here would just fail
 						// (kCross: the jump's last step has crossed it)
 						skip_group = (hl & !ok & !at_finest) | (ok & (kCross | !binade_bound));
+						if constexpr (REC) {
+							// two levels only: the whole map while the ray is above everything, then the record level for good.
+							// A refusal there is followed by a group; refusals in a row thin the attempts out (see `attempt`).
+							lev = lev == kTopLevel ? kTopLevel : kRecLevel;
+							fails = (ok | top) ? 0 : (fails_before < 6 ? fails_before + 1 : 6);
+							skip_group = (top & hl & !ok) | (ok & (kCross | !binade_bound));
+						}
 					}
 				}
 				diag.on_trip(f, LEAP, skip_group);
@@ -599,7 +654,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 	return pid.tile_y;
 }
 
-template <int PROJ, bool STATS, int GWM, bool LEAP, int SAMP>
+template <int PROJ, bool STATS, int GWM, int LEAP, int SAMP>
 __global__ __launch_bounds__(kBlockThreads, HMRM_MIN_WAVES) HMRM_OCCUPANCY_ATTR void k_render_fast(const DevFrame f, const RowMap rows,
                                                      const double *__restrict__ thr,
                                                      const uint32_t *__restrict__ cmap,
@@ -731,32 +786,98 @@ hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *
 	return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- window records ----
+// One thread per window of the record level: the nine highest cells of its 16 x 16 (clipped at the map's edge, NaN ignored
+// as in the pyramid), kept sorted by insertion -- most cells fail the first comparison.  The ninth is max2; the eight
+// above it are recorded where they are strictly higher.
+__global__ __launch_bounds__(256) void k_build_records(const double *__restrict__ thr, int map_w, int map_h,
+                                                       WindowRecord *__restrict__ dst, int rw, int rh) {
+	const int ix = (int)(blockIdx.x * 16u + (threadIdx.x & 15u)), iy = (int)(blockIdx.y * 16u + (threadIdx.x >> 4));
+	if (ix >= rw || iy >= rh) return;
+	constexpr int S = win_cells(kRecLevel), N = kRecCells + 1;
+	const int wx0 = ix << mip_stride_shift(kRecLevel), wy0 = iy << mip_stride_shift(kRecLevel);
+	double t[N];
+	uint32_t at[N]; // row << 8 | column inside the window
+#pragma unroll
+	for (int j = 0; j < N; ++j) {
+		t[j] = -__builtin_huge_val();
+		at[j] = 0xffffu;
+	}
+	for (int r = 0; r < S && wy0 + r < map_h; ++r) {
+		const double *row = thr + (size_t)(wy0 + r) * (size_t)map_w + wx0;
+		for (int c = 0; c < S && wx0 + c < map_w; ++c) {
+			const double v = row[c];
+			if (!(v > t[N - 1])) continue; // (NaN too)
+			t[N - 1] = v;
+			at[N - 1] = (uint32_t)(r << 8 | c);
+#pragma unroll
+			for (int j = N - 1; j > 0; --j) {
+				const bool up = t[j] > t[j - 1];
+				const double tv = t[j];
+				const uint32_t ta = at[j];
+				t[j] = up ? t[j - 1] : t[j];
+				at[j] = up ? at[j - 1] : at[j];
+				t[j - 1] = up ? tv : t[j - 1];
+				at[j - 1] = up ? ta : at[j - 1];
+			}
+		}
+	}
+	WindowRecord rec;
+	rec.max2 = round_up_to_float(t[N - 1]);
+	rec.spare0 = 0u;
+	rec.spare1[0] = rec.spare1[1] = 0u;
+	uint32_t xs[2] = {0u, 0u}, ys[2] = {0u, 0u};
+#pragma unroll
+	for (int j = 0; j < kRecCells; ++j) {
+		const bool keep = t[j] > t[N - 1];
+		xs[j >> 2] |= (keep ? (at[j] & 0xffu) : 0xffu) << (8 * (j & 3));
+		ys[j >> 2] |= (keep ? (at[j] >> 8) : 0xffu) << (8 * (j & 3));
+	}
+	rec.xs[0] = xs[0]; rec.xs[1] = xs[1];
+	rec.ys[0] = ys[0]; rec.ys[1] = ys[1];
+	dst[(size_t)iy * (size_t)rw + ix] = rec;
+}
+
+hipError_t launch_build_records(const double *d_thr, int map_w, int map_h, WindowRecord *d_dst, hipStream_t stream) {
+	const int rw = rec_row(map_w), rh = (map_h + 3) >> 2;
+	const dim3 grid((unsigned)((rw + 15) / 16), (unsigned)((rh + 15) / 16));
+	if (grid.y > 65535u) return hipErrorInvalidValue; // (api.cpp does not build records for such maps)
+	hipLaunchKernelGGL(k_build_records, grid, dim3(256), 0, stream, d_thr, map_w, map_h, d_dst, rw, rh);
+	return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- launch ----
-template <int PROJ, bool STATS, int GWM, bool LEAP>
+template <int PROJ, bool STATS, int GWM, int LEAP>
 static void launch_one(const DevFrame &f, const RowMap &rows, const double *d_thr, const uint32_t *d_cmap,
                        uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid, int tiles_y,
                        hipStream_t stream) {
-	if (f.sampling == 1)
-		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, 1>), grid, dim3(kBlockThreads), 0, stream, f, rows,
-		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
-	else if (f.sampling == 2) // (d_thr is the float table here, see launch_render_fast)
-		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, 2>), grid, dim3(kBlockThreads), 0, stream, f, rows,
-		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
-	else
+	if constexpr (LEAP == kRecords) { // (nearest sampling only: launch_render_fast has checked)
 		hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, 0>), grid, dim3(kBlockThreads), 0, stream, f, rows,
 		                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
+	} else {
+		if (f.sampling == 1)
+			hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, 1>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+			                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
+		else if (f.sampling == 2) // (d_thr is the float table here, see launch_render_fast)
+			hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, 2>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+			                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
+		else
+			hipLaunchKernelGGL((k_render_fast<PROJ, STATS, GWM, LEAP, 0>), grid, dim3(kBlockThreads), 0, stream, f, rows,
+			                   d_thr, d_cmap, d_out, out_stride_px, tiles_y, st);
+	}
 }
 
 template <int PROJ, bool STATS, int GWM>
-static void launch_leap(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
+static void launch_leap(FastKernel kernel, const DevFrame &f, const RowMap &rows, const double *d_thr,
                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
                         int tiles_y, hipStream_t stream) {
-	if (leap) launch_one<PROJ, STATS, GWM, true>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
-	else launch_one<PROJ, STATS, GWM, false>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	if (kernel == kLeaps) launch_one<PROJ, STATS, GWM, kLeaps>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	else if (kernel == kRecords) launch_one<PROJ, STATS, GWM, kRecords>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	else launch_one<PROJ, STATS, GWM, kPlainGroups>(f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 }
 
 template <int PROJ, bool STATS>
-static void launch_gwm(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
+static void launch_gwm(FastKernel leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                        const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
                        int tiles_y, hipStream_t stream) {
 	switch (f.grid_mode) {
@@ -767,7 +888,7 @@ static void launch_gwm(bool leap, const DevFrame &f, const RowMap &rows, const d
 }
 
 template <bool STATS>
-static void launch_proj(bool leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
+static void launch_proj(FastKernel leap, const DevFrame &f, const RowMap &rows, const double *d_thr,
                         const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px, StatsOut st, dim3 grid,
                         int tiles_y, hipStream_t stream) {
 	switch (f.projection) {
@@ -817,7 +938,14 @@ hipError_t launch_thr_to_float(const double *d_thr, float *d_thr32, int64_t n, h
 hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const double *d_thr_f64, const float *d_thr32,
                               const uint32_t *d_cmap, uint32_t *d_out, int64_t out_stride_px,
                               unsigned long long *d_counters, uint32_t *d_steps, double *d_entry, bool stats,
-                              bool leap, hipStream_t stream) {
+                              FastKernel kernel, const WindowRecord *d_records, hipStream_t stream) {
+	if (kernel == kRecords && (f.sampling != 0 || !d_records)) return hipErrorInvalidValue;
+	DevFrame with_records;
+	if (kernel == kRecords) { // (the record kernel finds its table where the bilinear mode finds its pyramid: frame.hpp)
+		with_records = f;
+		with_records.mipbuf_bil = reinterpret_cast<const float *>(d_records);
+	}
+	const DevFrame &fr = kernel == kRecords ? with_records : f;
 	const double *d_thr = f.sampling == 2 ? reinterpret_cast<const double *>(d_thr32) : d_thr_f64;
 	const int tiles_x = (f.screen_w + kTileW - 1) / kTileW;
 	const int tiles_y = (rows.local_rows + kTileH - 1) / kTileH;
@@ -865,8 +993,8 @@ hipError_t launch_render_fast(const DevFrame &f, const RowMap &rows, const doubl
 		}
 	}
 #endif
-	if (stats) launch_proj<true>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
-	else launch_proj<false>(leap, f, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	if (stats) launch_proj<true>(kernel, fr, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
+	else launch_proj<false>(kernel, fr, rows, d_thr, d_cmap, d_out, out_stride_px, st, grid, tiles_y, stream);
 	return hipGetLastError();
 }
 

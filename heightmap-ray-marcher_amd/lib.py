@@ -344,7 +344,7 @@ class Scene:
         return np.array(pos[:]), np.array(dirv[:]), d.value
 
     def kernel_choice(self) -> int:
-        """0 production kernel (leaps), 1 plain groups (forced, or chosen by the scene's probe), 2 literal loop."""
+        """0 production kernel (leaps), 1 plain groups, 2 literal loop, 3 groups + window records (1 / 3: forced, or chosen by the scene's probe)."""
         return int(lib.hmrm_debug_kernel_choice(self._h))
 
     def bench_kernel_ms(self, cam: Camera, iters: int) -> float:

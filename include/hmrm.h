@@ -282,10 +282,13 @@ int hmrm_debug_rcp_error(int32_t mode, uint64_t count, uint64_t seed, int32_t ex
 int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_t *plane_shift, int32_t *levels);
 
 /* Which kernel full frames of this scene are rendered with: 0 = the production kernel (speculative groups + exact
- * leaps), 1 = the speculative groups alone, 2 = the literal loop.  1 without HMRM_KERNEL=group means the scene's
- * one-time probe (part of the launch-order calibration of the first camera that is rendered repeatedly, or -- for
- * cameras that never repeat -- the scene's sixth full frame launched twice) measured the plain groups at least 3 %
- * faster on this content -- maps on which rays cannot jump. */
+ * leaps over the window-maximum pyramid), 1 = the speculative groups alone, 2 = the literal loop, 3 = the speculative
+ * groups with leaps over window records (a 16-cell window's maximum without its 8 highest cells, and where those stand:
+ * nearest-sampling frames; frames of the other sampling modes keep the production kernel then).  1 or 3 without
+ * HMRM_KERNEL=group / rec means the scene's one-time probe (part of the launch-order calibration of the first camera
+ * that is rendered repeatedly, or -- for cameras that never repeat -- the scene's sixth full frame launched twice)
+ * measured that kernel at least 3 % faster on this content -- maps on which rays cannot jump over whole windows: needles
+ * on a plateau, white noise. */
 int hmrm_debug_kernel_choice(const hmrm_scene *scene);
 
 /* The environment knobs (HMRM_KERNEL, HMRM_STEP_CAP, ...) are read once, when a

@@ -26,8 +26,10 @@ def _bits(a):
 
 
 # HMRM_KERNEL: "leap" = production kernel (speculative groups + exact leaps), "group" = groups
-# only, "simple" = the literal one-step loop.  All must agree with the oracle bit for bit.
-KERNEL_VARIANTS = ("leap", "group", "simple")
+# only, "simple" = the literal one-step loop, "rec" = groups + leaps over window records (nearest sampling; the plain
+# groups otherwise).  All must agree with the oracle bit for bit.
+KERNEL_VARIANTS = ("leap", "group", "simple", "rec")
+KERNEL_NAMES = ("the production kernel", "the plain groups", "the literal loop", "the groups with window records")  # Scene.kernel_choice()
 
 
 @contextlib.contextmanager
@@ -202,7 +204,7 @@ def test_baseline_config_full_size_subsampled_and_properties(gpu, oracle, wl_nam
     fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
     fb2 = scene.render(cam)
     assert np.array_equal(fb, fb2), "instrumented and plain kernels differ"
-    for variant in ("group", "simple"):
+    for variant in ("group", "simple", "rec"):
         with kernel_variant(variant):
             fbv, stv, stepsv, _ = scene.render_stats(cam, per_pixel=True)
         assert np.array_equal(fbv, fb), f"kernel variant {variant} differs from the production kernel"
@@ -240,7 +242,7 @@ def test_hostile_content_full_frames_match_oracle(gpu, oracle, kind):
     assert capped == 0 and st.capped == 0 and st.steps == total and total > 0
     assert np.array_equal(fb, ofb) and np.array_equal(scene.render(cam), ofb)
     assert np.array_equal(steps.astype(np.int64), osteps) and np.array_equal(_bits(entry), _bits(oentry))
-    for variant in ("group", "simple"):
+    for variant in ("group", "simple", "rec"):
         with kernel_variant(variant):
             assert np.array_equal(scene.render(cam), ofb), variant
     # the spherical headline camera over the same map (C3's pose scaled to this map), every 8th row
@@ -272,8 +274,8 @@ def test_kernel_probe_never_changes_a_pixel(gpu, oracle):
         for k in range(16):  # (first launch, 2 x up to 4 measured trials, settled launches)
             assert np.array_equal(scene.render(cam), ofb), (kind, k)
         choice = scene.kernel_choice()
-        print(f"{kind}: the probe chose {('the production kernel', 'the plain groups')[choice]}")
-        assert choice in (0, 1) and (expect is None or choice == expect)
+        print(f"{kind}: the probe chose {KERNEL_NAMES[choice]}")
+        assert choice in (0, 1, 3) and (expect is None or choice == expect)
         # another camera of the same scene renders with the scene's verdict: still the oracle's pixels
         cam2 = wl.camera(5, 64)
         ofb2, *_ = oracle.render(oracle.make_cfg(cam2, params, wl.map_size, wl.map_size), heights, cmap)
@@ -311,8 +313,8 @@ def test_shadow_probe_for_cameras_that_never_repeat(gpu, oracle):
         cam.width, cam.height = 640, 360
         ofb, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap)
         assert np.array_equal(scene.render(cam), ofb), k
-    print("needles under a moving camera: the shadow probe chose", ("the production kernel", "the plain groups")[scene.kernel_choice()])
-    assert scene.kernel_choice() in (0, 1)
+    print("needles under a moving camera: the shadow probe chose", KERNEL_NAMES[scene.kernel_choice()])
+    assert scene.kernel_choice() in (0, 1, 3)
     scene.close()
     # capped rays in the doubled frame are reported once
     with env(HMRM_STEP_CAP=60):
@@ -362,7 +364,7 @@ def test_no_probe_flag_keeps_a_frame_from_being_launched_twice(gpu, oracle):
         cam = frame(k, False)
     ofb, *_ = oracle.render(oracle.make_cfg(cam, params, wl.map_size, wl.map_size), heights, cmap)
     assert np.array_equal(out.cpu().numpy(), ofb)
-    print("needles, unflagged frames: the shadow probe chose", ("the production kernel", "the plain groups")[scene.kernel_choice()])
+    print("needles, unflagged frames: the shadow probe chose", KERNEL_NAMES[scene.kernel_choice()])
     scene.close()
 
 
@@ -710,6 +712,68 @@ def test_random_cameras_and_parameters_fuzz(gpu, oracle):
     finally:
         del os.environ["HMRM_STEP_CAP"]
     assert checked == 48 and leaped > 0
+
+
+def test_record_kernel_on_sparse_tall_cells_fuzz(gpu, oracle):
+    """The record kernel (HMRM_KERNEL=rec, frame.hpp WindowRecord: a 16-cell window's maximum without its 8 highest
+    cells, and where those stand) on the maps it is for -- flat or gently rolling ground with tall single cells at a
+    density of 1/8 .. 1/300, map sizes that clip the last windows, every projection, grid widths of all three kinds
+    -- frame, per-ray step counts and distance() bits against the oracle.  A path that grazes a recorded cell must be
+    refused, one that misses it by a hair must land exactly where the marched ray stands; a ray that leaves through the
+    map's low edge passes coordinates in (-1, 0), which the reference's truncation still counts as cell 0."""
+    rng = np.random.RandomState(20261005)
+    os.environ["HMRM_STEP_CAP"] = "400000"
+    checked = leaped = 0
+    try:
+        with kernel_variant("rec"):
+            for trial in range(60):
+                mw, mh = int(rng.choice([1, 3, 37, 64, 130, 257])), int(rng.choice([2, 33, 64, 131]))
+                ground = rng.randint(20, 60)
+                v = np.full((mh, mw), ground, dtype=np.uint8)
+                if trial % 3 == 1:  # rolling ground
+                    yy, xx = np.mgrid[0:mh, 0:mw]
+                    v = (ground + 12 * np.sin(xx / 9.0) * np.cos(yy / 7.0)).astype(np.uint8)
+                dens = float(rng.choice([1 / 8, 1 / 30, 1 / 64, 1 / 300]))
+                tall = rng.rand(mh, mw) < dens
+                v[tall] = rng.randint(180, 256, size=int(tall.sum())).astype(np.uint8) if trial % 2 else 255
+                rgb = np.ascontiguousarray(np.repeat(v[:, :, None], 3, axis=2))
+                cmap = rng.randint(0, 256, size=(mh, mw, 4)).astype(np.uint8)
+                gw = float(rng.choice([1.0, 1.0, 0.5, 0.05, 0.3, 1.7]))
+                lo = float(rng.choice([0.0, -1.5, 2.0]))
+                hi = lo + float(rng.uniform(2.0, 0.25 * max(mw, mh, 16))) * gw
+                params = gpu.SceneParams.make(lo, hi, grid_width=gw)
+                ext_x, ext_y = mw * gw, mh * gw
+                proj = int(rng.choice([1, 2, 3]))
+                ang = rng.uniform(0, 2 * np.pi)
+                dist = rng.uniform(0.0, 1.2) * max(ext_x, ext_y)
+                # cameras between the ground and the tops of the tall cells as often as above them
+                zc = lo + (hi - lo) * float(rng.uniform(0.15, 1.4))
+                pos = (ext_x / 2 + dist * np.cos(ang), -ext_y / 2 + dist * np.sin(ang), 2 * lo + zc)
+                hang = float(np.arctan2(-ext_y / 2 - pos[1], ext_x / 2 - pos[0]) + rng.uniform(-0.5, 0.5))
+                cam = gpu.Camera.make(width=int(rng.randint(24, 100)), height=int(rng.randint(16, 72)), projection=proj,
+                                      hfov=float(gpu.degrees_to_rads(rng.uniform(40, 175))), hang=hang,
+                                      vang=float(gpu.degrees_to_rads(rng.uniform(75, 150))), pos=pos,
+                                      ortho_width=float(rng.uniform(0.2, 3.0) * gw),
+                                      step_dist=float(rng.choice([0.05, 0.1, 0.25, 0.5, 1.0, 0.37]) * gw),
+                                      bg=tuple(int(b) for b in rng.randint(0, 256, size=3)))
+                heights = oracle.update_heightmap(rgb, params)
+                ofb, total, capped, osteps, oentry = oracle.render(oracle.make_cfg(cam, params, mw, mh, step_cap=400000),
+                                                                   heights, cmap, per_pixel=True)
+                scene = gpu.Scene(rgb, cmap, params)
+                fb, st, steps, entry = scene.render_stats(cam, per_pixel=True, allow_capped=True)
+                label = (trial, proj, gw, cam.step_dist, dens)
+                assert np.array_equal(_bits(entry), _bits(oentry)), label
+                assert np.array_equal(fb, ofb), label
+                if capped == 0:
+                    assert np.array_equal(steps.astype(np.int64), osteps) and st.steps == total, label
+                    assert np.array_equal(scene.render(cam), ofb), label
+                assert st.capped == capped, label
+                leaped += st.leaped_steps
+                checked += 1
+                scene.close()
+    finally:
+        del os.environ["HMRM_STEP_CAP"]
+    assert checked == 60 and leaped > 0
 
 
 def test_async_ring_frames_in_flight(gpu, oracle):
@@ -1176,7 +1240,7 @@ def test_float_heights_mode_bit_exact_vs_its_oracle_definition(gpu, oracle):
             heights = oracle.update_heightmap(rgb, params)
             cfg = oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0], step_cap=300000)
             ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True)
-            for variant in ("leap", "group"):
+            for variant in ("leap", "group", "rec"):
                 with kernel_variant(variant):
                     fb, st, steps, entry = scene.render_stats(cam, per_pixel=True, allow_capped=True)
                 ok = osteps >= 0
@@ -1421,7 +1485,7 @@ def test_bilinear_mode_bit_exact(gpu, oracle, case):
     cfg = oracle.make_cfg(cam, params, rgb.shape[1], rgb.shape[0])
     assert cfg.sampling == 1
     ofb, total, capped, osteps, oentry = oracle.render(cfg, heights, cmap, per_pixel=True)
-    for variant in ("leap", "group", "simple"):  # "simple" has no bilinear loop: served by "group"
+    for variant in ("leap", "group", "simple", "rec"):  # "simple" and "rec" have no bilinear loop: served by "group"
         with kernel_variant(variant):
             fb, st, steps, entry = scene.render_stats(cam, per_pixel=True)
             assert np.array_equal(_bits(entry), _bits(oentry)), variant

@@ -52,7 +52,7 @@ for kind in kinds:
             n = 2 if v == "simple" else 10
             med[v] = float(np.median([scene.bench_kernel_ms(cam, n) for _ in range(5)][1:]))
             if v == "auto":
-                chose = ("leap", "group", "simple")[scene.kernel_choice()]
+                chose = ("leap", "group", "simple", "rec")[scene.kernel_choice()]
             scene.close()
         nan = float("nan")
         ra, rl = med.get("auto", nan) / med.get("group", nan), med.get("leap", nan) / med.get("group", nan)

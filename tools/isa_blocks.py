@@ -6,7 +6,7 @@ import os, re, sys
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "heightmap-ray-marcher_amd", "csrc", "_build", "render_fast.s")
 s = open(path).read()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-want = args[0] if args else "ILi2ELb0ELi0ELb1ELi0E"
+want = args[0] if args else "ILi2ELb0ELi0ELi1ELi0E"
 parts = re.split(r'\t\.type\t(_ZN4hmrm13k_render_fastI[^,]+),@function\n', s)
 body = None
 for i in range(1, len(parts), 2):

@@ -76,7 +76,7 @@ def mangled(template_args):
 
 
 if __name__ == "__main__":
-    want = sys.argv[1] if len(sys.argv) > 1 else "ILi2ELb0ELi0ELb1ELi0E"
+    want = sys.argv[1] if len(sys.argv) > 1 else "ILi2ELb0ELi0ELi1ELi0E"
     blocks = blocks_of(want)
     if blocks is None:
         sys.exit("no such instantiation")

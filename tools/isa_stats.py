@@ -3,7 +3,7 @@ import os, re, sys
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "heightmap-ray-marcher_amd", "csrc", "_build", "render_fast.s")
 s = open(path).read()
 parts = re.split(r'\t\.type\t(_ZN4hmrm13k_render_fastI[^,]+),@function\n', s)
-want = sys.argv[1:] or ["ILi2ELb0ELi0ELb1ELi0E", "ILi1ELb0ELi0ELb1ELi0E", "ILi3ELb0ELi0ELb1ELi0E"]
+want = sys.argv[1:] or ["ILi2ELb0ELi0ELi1ELi0E", "ILi1ELb0ELi0ELi1ELi0E", "ILi3ELb0ELi0ELi1ELi0E"]
 for i in range(1, len(parts), 2):
     if not any(w in parts[i] for w in want):
         continue

@@ -2,7 +2,7 @@
 # Round-5 profile round on the GPU box (via gpurun): the bench line, the rocprofv3 kernel trace + stats of the headline
 # loop, separate PMC passes (counters only with --kernel-trace) for C3, C3h and -- fetch / write only -- the literal
 # kernel on C3 (WLS="C3 C3h C5 C2 C4" for more workloads).  Summarise afterwards, here:
-#   python tools/pmc_summary.py gpurun_out/prof_r05_C3 C3 profiles/r05_C3_rocprof      (likewise C3h, C3_literal, C3_group)
+#   python tools/pmc_summary.py gpurun_out/prof_r05_C3 C3 profiles/r05_C3_rocprof      (likewise C3h, C3_literal, C3_group, C3_needles_rec)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 pmc() { # <outdir> <workload> <variant> <launches> <counters...>
@@ -35,3 +35,12 @@ pmc "$out/fetch" C3 group 6 FETCH_SIZE TCC_HIT_sum
 pmc "$out/write" C3 group 6 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
 pmc "$out/sq" C3 group 6 SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
 echo "group done"
+# the record kernel on the map it is for: groups + leaps over window records, C3's camera over needles on a plateau
+out=gpurun_out/prof_r05_C3_needles_rec
+rm -rf "$out"; mkdir -p "$out"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python tools/prof_run.py C3/needles rec 30 > "$out/run_under_rocprof.log" 2>&1
+pmc "$out/fetch" C3/needles rec 20 FETCH_SIZE TCC_HIT_sum
+pmc "$out/write" C3/needles rec 20 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
+pmc "$out/sq" C3/needles rec 20 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD
+pmc "$out/sq2" C3/needles rec 20 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
+echo "records done"
