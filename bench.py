@@ -906,6 +906,20 @@ def main(argv=None):
                                "group_kernel_ms": group_ms, "over_group": leap_ms / group_ms, "ray_steps_per_frame": int(sr.steps),
                                "value": int(sr.steps) / (leap_ms * 1e-3), "mrays_per_s": int(sr.rays) / (leap_ms * 1e-3) / 1e6,
                                "executed_per_frame": executed(sr)}
+                if kind == "needles" and wl.name == "C3":
+                    # the record kernel's own rocprofv3 / PMC round (tools/profile_r05.sh, last leg): what bounds it
+                    rp, rprov = _pmc_from_profiles("C3_needles_rec", hmrm.kernel_src_sha())
+
+                    def rec():
+                        sc.bench_kernel_ms(cr, 2)
+                        return sc.bench_kernel_ms(cr, n_r)
+                    rec_ms = with_kernel("rec", rec)
+                    rough[kind]["record_kernel"] = {
+                        "kernel": "k_render_fast<.., LEAP = 2> (HMRM_KERNEL=rec): groups of 6 positions + leaps over 16-cell windows whose 8 highest "
+                                  "cells the path misses (frame.hpp WindowRecord)",
+                        "kernel_ms": rec_ms, "over_group": rec_ms / group_ms,
+                        "rocprof_mean_us": (rp or {}).get("kernel_us_per_frame_rocprof"), "lane_util": (rp or {}).get("lane_util"),
+                        "hbm_bytes_per_launch": (rp or {}).get("hbm_bytes_per_launch"), "wave_time": (rp or {}).get("wave_time"), "pmc": rprov}
                 sc.close()
             rough["note"] = ("same camera as the headline (canyon: low and level, down the corridor); kernel_ms = the library as shipped "
                              f"(HIP events, {n_r} launches): the production kernel unless the scene's one-time probe measured the other kernel -- "

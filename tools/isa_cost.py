@@ -69,10 +69,12 @@ def loop_cost(want, asm_path=path):
 
 
 def mangled(template_args):
-    """'2, false, 0, true, 0' (as rocprofv3 prints the kernel) -> the Itanium-mangled argument list."""
+    """'2, false, 0, 1, 0' (as rocprofv3 prints the kernel; the fourth argument -- 0 plain groups, 1 leaps, 2 records -- was a
+    bool until round 5's record kernel) -> the Itanium-mangled argument list."""
     p, stats, gwm, leap, samp = [a.strip() for a in template_args.split(",")]
     b = lambda x: "1" if x == "true" else "0"
-    return f"ILi{p}ELb{b(stats)}ELi{gwm}ELb{b(leap)}ELi{samp}E"
+    leap = {"true": "1", "false": "0"}.get(leap, leap)
+    return f"ILi{p}ELb{b(stats)}ELi{gwm}ELi{leap}ELi{samp}E"
 
 
 if __name__ == "__main__":
