@@ -1787,6 +1787,23 @@ int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_
 	return fits ? 1 : 0;
 }
 
+// Test hook: the scene's window records (frame.hpp WindowRecord, 32 bytes each, rec_row(map_w) x ceil(map_h / 4)) and the
+// threshold table they were built from (map_w x map_h doubles), copied to the host.  Either pointer may be NULL.
+int hmrm_debug_read_records(const hmrm_scene *cs, void *records_out, double *thr_out) {
+	hmrm_scene *s = const_cast<hmrm_scene *>(cs);
+	if (!s) return fail(HMRM_E_ARG, "NULL argument");
+	std::lock_guard<std::mutex> lk(s->mu);
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	if (records_out) {
+		if (!s->d_records) return fail(HMRM_E_ARG, "this scene has no window records (map too tall)");
+		HIP_TRY(hipMemcpy(records_out, s->d_records, (size_t)hmrm::rec_row(s->map_w) * (size_t)((s->map_h + 3) / 4) * sizeof(hmrm::WindowRecord),
+		                  hipMemcpyDeviceToHost));
+	}
+	if (thr_out) HIP_TRY(hipMemcpy(thr_out, s->d_thr, (size_t)s->map_w * (size_t)s->map_h * sizeof(double), hipMemcpyDeviceToHost));
+	return HMRM_OK;
+}
+
 // Test hook (no GPU): the calibration's state machine (launch_order.hpp OrderCalibration / KernelChoice) driven through a
 // sequence of full-frame launches of one camera; the measurement of a launch arrives before the next launch.
 int hmrm_debug_calibrate(const uint64_t *records, int32_t launches, int32_t tile_rows, int32_t rot, int32_t may_probe,

@@ -69,6 +69,15 @@ constexpr int kGroup = HMRM_GROUP; // U: positions per speculative group of the 
 #define HMRM_GROUP_PLAIN 6
 #endif
 constexpr int kGroupPlain = HMRM_GROUP_PLAIN;
+// ... and of the record kernel; the most refusals in a row its back-off counts (attempts every 2^n-th trip at most)
+#ifndef HMRM_GROUP_REC
+#define HMRM_GROUP_REC 6
+#endif
+constexpr int kGroupRec = HMRM_GROUP_REC;
+#ifndef HMRM_REC_BACKOFF
+#define HMRM_REC_BACKOFF 6
+#endif
+constexpr int kRecBackoff = HMRM_REC_BACKOFF;
 #ifndef HMRM_MIN_LEAP
 #define HMRM_MIN_LEAP 2
 #endif
@@ -174,7 +183,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
                                                 int wave, int lane) {
 	constexpr bool BILINEAR = SAMP == 1, F32 = SAMP == 2;
 	constexpr bool REC = LEAP == 2;                     // leaps over window records instead of the pyramid (frame.hpp WindowRecord)
-	constexpr int U = LEAP == 1 ? kGroup : kGroupPlain; // positions per speculative group
+	constexpr int U = LEAP == 1 ? kGroup : (REC ? kGroupRec : kGroupPlain); // positions per speculative group
 	static_assert(!REC || SAMP == 0, "records bound the nearest cell's double thresholds only");
 	const float *__restrict__ thr32 = reinterpret_cast<const float *>(thr);
 	const float *__restrict__ mip = BILINEAR ? f.mipbuf_bil : f.mipbuf; // the pyramid this sampling mode leaps on
@@ -493,7 +502,7 @@ __device__ __forceinline__ int render_wave_tile(const DevFrame &f, const RowMap 
 							// two levels only: the whole map while the ray is above everything, then the record level for good.
 							// A refusal there is followed by a group; refusals in a row thin the attempts out (see `attempt`).
 							lev = lev == kTopLevel ? kTopLevel : kRecLevel;
-							fails = (ok | top) ? 0 : (fails_before < 6 ? fails_before + 1 : 6);
+							fails = (ok | top) ? 0 : (fails_before < kRecBackoff ? fails_before + 1 : kRecBackoff);
 							skip_group = (top & hl & !ok) | (ok & (kCross | !binade_bound));
 						}
 					}
@@ -788,8 +797,8 @@ hipError_t launch_build_mip_up(const float *d_src, int src_w, int src_h, float *
 
 // ---------------------------------------------------------------- window records ----
 // One thread per window of the record level: the nine highest cells of its 16 x 16 (clipped at the map's edge, NaN ignored
-// as in the pyramid), kept sorted by insertion -- most cells fail the first comparison.  The ninth is max2; the eight
-// above it are recorded where they are strictly higher.
+// as in the pyramid), kept sorted by insertion.  The ninth is max2; the eight above it are recorded where they are
+// strictly higher.
 __global__ __launch_bounds__(256) void k_build_records(const double *__restrict__ thr, int map_w, int map_h,
                                                        WindowRecord *__restrict__ dst, int rw, int rh) {
 	const int ix = (int)(blockIdx.x * 16u + (threadIdx.x & 15u)), iy = (int)(blockIdx.y * 16u + (threadIdx.x >> 4));
@@ -803,12 +812,26 @@ __global__ __launch_bounds__(256) void k_build_records(const double *__restrict_
 		t[j] = -__builtin_huge_val();
 		at[j] = 0xffffu;
 	}
+	// A row at a time: its 16 loads are in flight together (one load per trip of a cell loop left the kernel waiting for
+	// memory 256 times per window), and a row whose maximum does not reach the ninth-highest so far -- most rows -- costs
+	// 16 maxima and one comparison.
+	const int cols = min(S, map_w - wx0); // (>= 1)
 	for (int r = 0; r < S && wy0 + r < map_h; ++r) {
 		const double *row = thr + (size_t)(wy0 + r) * (size_t)map_w + wx0;
-		for (int c = 0; c < S && wx0 + c < map_w; ++c) {
-			const double v = row[c];
-			if (!(v > t[N - 1])) continue; // (NaN too)
-			t[N - 1] = v;
+		double v[S];
+#pragma unroll
+		for (int c = 0; c < S; ++c) {
+			const double x = row[c < cols ? c : cols - 1]; // (never past the row's end)
+			v[c] = c < cols ? x : -__builtin_huge_val();
+		}
+		double m = v[0];
+#pragma unroll
+		for (int c = 1; c < S; ++c) m = __builtin_fmax(m, v[c]); // (fmax skips NaN, as the pyramid does)
+		if (!(m > t[N - 1])) continue;
+#pragma unroll
+		for (int c = 0; c < S; ++c) {
+			if (!(v[c] > t[N - 1])) continue; // (NaN too)
+			t[N - 1] = v[c];
 			at[N - 1] = (uint32_t)(r << 8 | c);
 #pragma unroll
 			for (int j = N - 1; j > 0; --j) {

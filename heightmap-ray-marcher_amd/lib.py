@@ -109,6 +109,7 @@ def _load():
         "hmrm_scene_take_capped": (C.c_int, [vp, vp, C.POINTER(C.c_uint64)]),
         "hmrm_debug_reload_env": (C.c_int, [vp]),
         "hmrm_debug_kernel_choice": (C.c_int, [vp]),
+        "hmrm_debug_read_records": (C.c_int, [vp, vp, vp]),
         "hmrm_debug_calibrate": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "hmrm_debug_mip_layout": (C.c_int, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "hmrm_band_local_rows": (i32, [i32, i32, i32, i32]),
@@ -342,6 +343,17 @@ class Scene:
         pos, dirv, d = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
         _check(lib.hmrm_debug_ray(self._h, C.byref(cam), px, py, pos, dirv, C.byref(d)))
         return np.array(pos[:]), np.array(dirv[:]), d.value
+
+    def read_records(self):
+        """(records, thr): the window records as a structured array of shape (ceil(map_h / 4), ceil(map_w / 4)) with fields
+        max2 / xs / ys, and the threshold table (map_h x map_w doubles) they were built from."""
+        rw, rh = (self.map_w + 3) // 4, (self.map_h + 3) // 4
+        dt = np.dtype([("max2", np.float32), ("spare0", np.uint32), ("xs", np.uint8, 8), ("ys", np.uint8, 8), ("spare1", np.uint32, 2)])
+        assert dt.itemsize == 32
+        recs = np.empty((rh, rw), dtype=dt)
+        thr = np.empty((self.map_h, self.map_w), dtype=np.float64)
+        _check(lib.hmrm_debug_read_records(self._h, recs.ctypes.data_as(C.c_void_p), thr.ctypes.data_as(C.c_void_p)))
+        return recs, thr
 
     def kernel_choice(self) -> int:
         """0 production kernel (leaps), 1 plain groups, 2 literal loop, 3 groups + window records (1 / 3: forced, or chosen by the scene's probe)."""

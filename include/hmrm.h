@@ -291,6 +291,15 @@ int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_
  * on a plateau, white noise. */
 int hmrm_debug_kernel_choice(const hmrm_scene *scene);
 
+/* Test hook: the scene's window records -- one 32-byte record per 16 x 16-cell window of the map, a window every 4 cells,
+ * ceil(map_w / 4) per row and ceil(map_h / 4) rows: { float max2; uint32 spare; uint8 xs[8]; uint8 ys[8]; uint32 spare[2] },
+ * max2 = the window's maximum hit threshold without its 8 highest cells (rounded up to float), xs / ys = where the cells
+ * strictly above it stand inside the window (255: slot unused) -- and the threshold table they were built from
+ * (heightmap_buf[i] + min_height, main/hmap.cpp:1013-1016; map_w x map_h doubles), copied to the host.  Either pointer
+ * may be NULL.  The record kernel (hmrm_debug_kernel_choice 3) leaps across a window when the ray stays at or above max2
+ * and its path misses the recorded cells; no counterpart in the reference, which samples every step. */
+int hmrm_debug_read_records(const hmrm_scene *scene, void *records_out, double *thr_out);
+
 /* The environment knobs (HMRM_KERNEL, HMRM_STEP_CAP, ...) are read once, when a
  * scene is created; this re-reads them for a live scene (tests and tools switch kernel variants).  Launch orders
  * calibrated so far are forgotten (they were measured on the old kernel variant). */

@@ -714,6 +714,45 @@ def test_random_cameras_and_parameters_fuzz(gpu, oracle):
     assert checked == 48 and leaped > 0
 
 
+def test_window_records_are_the_ninth_highest_and_the_cells_above_it(gpu):
+    """k_build_records against numpy on the device's own threshold table: every 16 x 16 window (one every 4 cells, clipped
+    at the map's edge) holds max2 = its ninth-highest threshold rounded UP to float (-inf with fewer than nine cells) and
+    exactly the cells strictly above that value -- at most eight by construction; ties at the ninth value are not recorded."""
+    rng = np.random.RandomState(7)
+    for mw, mh, kind in ((64, 48, "needles"), (37, 21, "noise"), (130, 9, "ties"), (3, 70, "noise"), (1, 1, "flat"), (257, 33, "rolling")):
+        if kind == "needles":
+            v = np.where(rng.rand(mh, mw) < 1 / 20, 255, 40)
+        elif kind == "noise":
+            v = rng.randint(0, 256, size=(mh, mw))
+        elif kind == "ties":
+            v = np.where(rng.rand(mh, mw) < 1 / 6, 200, np.where(rng.rand(mh, mw) < 0.5, 90, 30))
+        elif kind == "flat":
+            v = np.full((mh, mw), 77)
+        else:
+            yy, xx = np.mgrid[0:mh, 0:mw]
+            v = (100 + 60 * np.sin(xx / 11.0) * np.cos(yy / 5.0)).astype(np.int64)
+        v8 = v.astype(np.uint8)
+        rgb = np.ascontiguousarray(np.repeat(v8[:, :, None], 3, axis=2))
+        scene = gpu.Scene(rgb, np.zeros((mh, mw, 4), dtype=np.uint8), gpu.SceneParams.make(-1.5, 23.0, grid_width=0.7))
+        recs, thr = scene.read_records()
+        scene.close()
+        assert recs.shape == ((mh + 3) // 4, (mw + 3) // 4)
+        for iy in range(recs.shape[0]):
+            for ix in range(recs.shape[1]):
+                win = thr[iy * 4:iy * 4 + 16, ix * 4:ix * 4 + 16]
+                order = np.sort(win.ravel())[::-1]
+                ninth = order[8] if order.size > 8 else -np.inf
+                want2 = np.float32(ninth)
+                if float(want2) < ninth:
+                    want2 = np.nextafter(want2, np.float32(np.inf))
+                r = recs[iy, ix]
+                assert r["max2"] == want2 or (np.isneginf(want2) and np.isneginf(r["max2"])), (kind, ix, iy)
+                got = {(int(x), int(y)) for x, y in zip(r["xs"], r["ys"]) if x != 255 or y != 255}
+                ys, xs = np.nonzero(win > ninth)
+                assert got == {(int(x), int(y)) for x, y in zip(xs, ys)}, (kind, ix, iy)
+                assert all((x == 255) == (y == 255) for x, y in zip(r["xs"], r["ys"]))
+
+
 def test_record_kernel_on_sparse_tall_cells_fuzz(gpu, oracle):
     """The record kernel (HMRM_KERNEL=rec, frame.hpp WindowRecord: a 16-cell window's maximum without its 8 highest
     cells, and where those stand) on the maps it is for -- flat or gently rolling ground with tall single cells at a
