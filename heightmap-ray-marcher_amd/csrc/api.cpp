@@ -200,6 +200,7 @@ struct hmrm_scene {
 	double thr_max = 0.0;
 	double thr_max_bil = 0.0; // whole-map bound of the interpolated thresholds (bilinear mode)
 	bool bil_valid = false;
+	bool records_valid = false; // d_records describes the current heights (ensure_records)
 	float *d_mipbuf_bil = nullptr; // the same over the 3x3-dilated table (bilinear quality mode)
 	float *d_mipbuf = nullptr; // window maxima over d_thr: 4/8/../256-cell windows every 2/4/../128 cells
 	hmrm::WindowRecord *d_records = nullptr; // frame.hpp: the 16-cell windows' maxima without their 8 highest cells, and those cells (null: map too tall for the build's grid)
@@ -337,6 +338,7 @@ int check_camera(const hmrm_camera *cam) {
 }
 
 int ensure_bilinear_pyramid(hmrm_scene *s);
+int ensure_records(hmrm_scene *s);
 
 void to_host_camera(const hmrm_camera *cam, hmrm::HostCamera *hc) {
 	*hc = hmrm::HostCamera{};
@@ -572,6 +574,10 @@ int launch_shadow_probe(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, co
 	measured.measure = c->d_meas;
 	const bool records_ok = f.sampling == 0 && s->d_records; // (the other kernel of this frame: launch_kernel)
 	s->choice.with_records = records_ok;
+	if (records_ok) {
+		const int rc_r = ensure_records(s);
+		if (rc_r) return rc_r;
+	}
 	for (int pass = 0; pass < 2; ++pass) {
 		HIP_TRY(hmrm::launch_measure_init(measured.measure, tiles_y, c->stream));
 		HIP_TRY(hmrm::launch_render_fast(f, measured, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
@@ -601,15 +607,11 @@ int launch_kernel(hmrm_scene *s, StreamCtx *c, const hmrm::DevFrame &f, const hm
 		HIP_TRY(hmrm::launch_render(f, rows_in_order, s->d_thr, s->d_cmap, d_out, out_stride_px, c->d_counters, d_steps,
 		                            d_entry, stats, c->stream));
 	} else {
-		// The other kernel: the plain groups, with leaps over window records where the sampling allows them (the records bound
-		// the nearest cell's double thresholds).  The probe's verdict holds for the frames that would run what it measured.
-		const bool records_ok = f.sampling == 0 && s->d_records;
-		hmrm::FastKernel k = hmrm::kLeaps;
-		if (s->knobs.kernel == 1) k = hmrm::kPlainGroups;
-		else if (s->knobs.kernel == 3) k = records_ok ? hmrm::kRecords : hmrm::kPlainGroups;
-		else if (use_group && !(s->choice.use_group && s->choice.with_records != records_ok)) {
-			k = records_ok ? hmrm::kRecords : hmrm::kPlainGroups;
-			if (!s->choice.use_group) s->choice.with_records = records_ok; // (a trial of the probe: this is what it measures)
+		// (the records bound the nearest cell's double thresholds: launch_order.hpp pick_fast_kernel)
+		const hmrm::FastKernel k = (hmrm::FastKernel)hmrm::pick_fast_kernel(s->knobs.kernel, use_group, f.sampling == 0 && s->d_records, s->choice);
+		if (k == hmrm::kRecords) {
+			const int rc_r = ensure_records(s);
+			if (rc_r) return rc_r;
 		}
 		HIP_TRY(hmrm::launch_render_fast(f, rows_in_order, s->d_thr, s->d_thr32, s->d_cmap, d_out, out_stride_px,
 		                                 c->d_counters, d_steps, d_entry, stats, k, s->d_records, c->stream));
@@ -747,6 +749,19 @@ int ensure_stats(hmrm_scene *s, size_t px) {
 	return HMRM_OK;
 }
 
+// The window records (frame.hpp), built the first time the record kernel is about to run after a height update -- by the
+// scene's probe, a verdict for it, or HMRM_KERNEL=rec -- so that a caller who changes the heights every frame, and is never
+// probed, does not pay for a table nobody reads (0.26-0.48 ms at 4096 x 4096).  Nothing reads the table while it is
+// written: a height update drains the scene's streams, and no record kernel has been launched since.
+int ensure_records(hmrm_scene *s) {
+	if (s->records_valid) return HMRM_OK;
+	if (!s->d_records) return fail(HMRM_E_ARG, "this scene has no window records");
+	HIP_TRY(hmrm::launch_build_records(s->d_thr, s->map_w, s->map_h, s->d_records, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	s->records_valid = true;
+	return HMRM_OK;
+}
+
 // Bilinear quality mode only: the second pyramid, over the 3x3-dilated (and margin-padded)
 // table, built the first time a bilinear frame is asked for after a height update.
 int ensure_bilinear_pyramid(hmrm_scene *s) {
@@ -808,8 +823,8 @@ int run_update_heights(hmrm_scene *s) {
 	for (int l = 1; l < hmrm::kMipLevels; ++l)
 		HIP_TRY(hmrm::launch_build_mip_up(s->plane(s->d_mipbuf, l - 1), s->mip_w[l - 1], s->mip_h[l - 1],
 		                                  s->plane(s->d_mipbuf, l), s->mip_w[l], s->mip_h[l], s->mip_row, l - 1, s->stream));
-	if (s->d_records) HIP_TRY(hmrm::launch_build_records(s->d_thr, s->map_w, s->map_h, s->d_records, s->stream));
 	s->bil_valid = false; // rebuilt by the next bilinear frame
+	s->records_valid = false; // ... and the window records by the next launch of the record kernel
 	for (StreamCtx *c : s->ctxs)
 		for (FrameSlot &sl : c->slots) sl.valid = false;
 	s->settled.clear();
@@ -1787,6 +1802,18 @@ int hmrm_debug_mip_layout(int32_t map_w, int32_t map_h, int32_t *mip_row, int32_
 	return fits ? 1 : 0;
 }
 
+// Test hook (no GPU): launch_order.hpp pick_fast_kernel for a scene whose probe state is (scene_verdict, scene_with_records).
+int hmrm_debug_pick_kernel(int32_t forced, int32_t use_other, int32_t records_ok, int32_t scene_verdict, int32_t scene_with_records,
+                           int32_t *with_records_after) {
+	hmrm::KernelChoice choice;
+	choice.use_group = scene_verdict != 0;
+	choice.probed = choice.use_group;
+	choice.with_records = scene_with_records != 0;
+	const int k = hmrm::pick_fast_kernel(forced, use_other != 0, records_ok != 0, choice);
+	if (with_records_after) *with_records_after = choice.with_records ? 1 : 0;
+	return k;
+}
+
 // Test hook: the scene's window records (frame.hpp WindowRecord, 32 bytes each, rec_row(map_w) x ceil(map_h / 4)) and the
 // threshold table they were built from (map_w x map_h doubles), copied to the host.  Either pointer may be NULL.
 int hmrm_debug_read_records(const hmrm_scene *cs, void *records_out, double *thr_out) {
@@ -1797,6 +1824,8 @@ int hmrm_debug_read_records(const hmrm_scene *cs, void *records_out, double *thr
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	if (records_out) {
 		if (!s->d_records) return fail(HMRM_E_ARG, "this scene has no window records (map too tall)");
+		const int rc_r = ensure_records(s);
+		if (rc_r) return rc_r;
 		HIP_TRY(hipMemcpy(records_out, s->d_records, (size_t)hmrm::rec_row(s->map_w) * (size_t)((s->map_h + 3) / 4) * sizeof(hmrm::WindowRecord),
 		                  hipMemcpyDeviceToHost));
 	}

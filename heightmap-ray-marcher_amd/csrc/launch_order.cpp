@@ -259,6 +259,16 @@ bool OrderCalibration::on_measured(const unsigned long long *rec, int tiles_y, i
 	return true;
 }
 
+int pick_fast_kernel(int forced, bool use_other, bool records_ok, KernelChoice &scene) {
+	const int other = records_ok ? 2 : 0;
+	if (forced == 1) return 0;
+	if (forced == 3) return other;
+	if (!use_other) return 1;
+	if (scene.use_group) return scene.with_records == records_ok ? other : 1;
+	scene.with_records = records_ok; // (a probe's launch)
+	return other;
+}
+
 void fold_shadow_probe(KernelChoice &scene, const unsigned long long *leap_rec, const unsigned long long *group_rec, int tiles_y) {
 	const double leap_span = std::max(1.0, measured_makespan(leap_rec, tiles_y));
 	const double group_span = std::max(1.0, measured_makespan(group_rec, tiles_y));

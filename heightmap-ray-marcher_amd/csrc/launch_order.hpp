@@ -88,6 +88,15 @@ struct OrderCalibration { // of one cached camera
 	void drop_in_flight() { in_flight = -1; }
 };
 
+// Which kernel a frame is launched with: 0 the plain groups, 1 pyramid leaps (production), 2 window records (the values of
+// render.hpp FastKernel).  `forced`: HMRM_KERNEL (0 none, 1 group, 3 rec); `use_other`: the launch plan or the scene's
+// verdict asks for the other kernel; `records_ok`: this frame could run the record kernel (nearest sampling, table there).
+// The other kernel is the record kernel where it can run, else the plain groups.  A verdict holds for the frames that would
+// run what the probe measured: one obtained with the records leaves bilinear / float-heights frames on the production
+// kernel, one obtained with the plain groups leaves nearest frames there.  A probe's own launch -- `use_other` while the
+// scene has no verdict -- notes in scene.with_records what it measures.
+int pick_fast_kernel(int forced, bool use_other, bool records_ok, KernelChoice &scene);
+
 // The shadow probe's verdict: one frame launched twice, production kernel then plain groups, both measured.
 void fold_shadow_probe(KernelChoice &scene, const unsigned long long *leap_rec, const unsigned long long *group_rec, int tiles_y);
 

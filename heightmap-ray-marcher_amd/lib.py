@@ -110,6 +110,7 @@ def _load():
         "hmrm_debug_reload_env": (C.c_int, [vp]),
         "hmrm_debug_kernel_choice": (C.c_int, [vp]),
         "hmrm_debug_read_records": (C.c_int, [vp, vp, vp]),
+        "hmrm_debug_pick_kernel": (C.c_int, [i32, i32, i32, i32, i32, C.POINTER(i32)]),
         "hmrm_debug_calibrate": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "hmrm_debug_mip_layout": (C.c_int, [i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "hmrm_band_local_rows": (i32, [i32, i32, i32, i32]),
@@ -390,6 +391,14 @@ def mip_layout(map_w: int, map_h: int):
     if rc < 0:
         raise HmrmError(rc, last_error())
     return row.value, shift.value, levels.value, bool(rc)
+
+
+def pick_kernel(forced=0, use_other=False, records_ok=True, verdict=False, verdict_with_records=False):
+    """launch_order.hpp pick_fast_kernel (no GPU) -> (kernel: 0 plain groups, 1 production, 2 records; what the scene remembers
+    as the probe's alternative afterwards)."""
+    after = C.c_int32()
+    k = lib.hmrm_debug_pick_kernel(int(forced), int(use_other), int(records_ok), int(verdict), int(verdict_with_records), C.byref(after))
+    return int(k), bool(after.value)
 
 
 def calibrate(records: np.ndarray, rot: int, may_probe=True, scene_already_probed=False, can_measure=None):

@@ -300,6 +300,15 @@ int hmrm_debug_kernel_choice(const hmrm_scene *scene);
  * and its path misses the recorded cells; no counterpart in the reference, which samples every step. */
 int hmrm_debug_read_records(const hmrm_scene *scene, void *records_out, double *thr_out);
 
+/* Test hook (no GPU): which kernel a frame is launched with -- returns 0 the plain groups, 1 the production kernel, 2 the
+ * record kernel -- given HMRM_KERNEL (`forced`: 0 none, 1 group, 3 rec), whether the launch plan or the scene's verdict
+ * asks for the other kernel, whether this frame could run the record kernel (nearest sampling), and the scene's probe
+ * state (verdict for the other kernel; obtained with the record kernel or with the plain groups).  A verdict holds for
+ * the frames that would run what was measured.  *with_records_after: what the scene remembers afterwards (a probe's own
+ * launch notes what it measures). */
+int hmrm_debug_pick_kernel(int32_t forced, int32_t use_other, int32_t records_ok, int32_t scene_verdict, int32_t scene_with_records,
+                           int32_t *with_records_after);
+
 /* The environment knobs (HMRM_KERNEL, HMRM_STEP_CAP, ...) are read once, when a
  * scene is created; this re-reads them for a live scene (tests and tools switch kernel variants).  Launch orders
  * calibrated so far are forgotten (they were measured on the old kernel variant). */

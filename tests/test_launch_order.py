@@ -150,3 +150,26 @@ def test_calibration_waits_while_it_cannot_measure(hmrm):
     flat[:, :, 1] = 500
     r = hmrm.calibrate(flat, 0)
     assert r["n_trials"] in (2, 3) and r["settled_at"] >= 4 and r["best"] in (0, r["n_trials"] - 1)
+
+
+def test_which_kernel_a_frame_is_launched_with(hmrm):
+    """launch_order.hpp pick_fast_kernel: the other kernel is the record kernel where the frame can run it (nearest sampling),
+    else the plain groups; a verdict holds for the frames that would run what the probe measured; HMRM_KERNEL overrides."""
+    PLAIN, LEAPS, RECORDS = 0, 1, 2
+    pick = hmrm.pick_kernel
+    # nothing asks for the other kernel: production, whatever the frame could run
+    assert pick(records_ok=True)[0] == LEAPS and pick(records_ok=False)[0] == LEAPS
+    # a probe's own launch (no verdict yet): the alternative of THIS frame, remembered
+    assert pick(use_other=True, records_ok=True) == (RECORDS, True)
+    assert pick(use_other=True, records_ok=False, verdict_with_records=True) == (PLAIN, False)
+    # a verdict obtained with the records: nearest frames run them, bilinear / float-heights frames keep the production kernel
+    assert pick(use_other=True, records_ok=True, verdict=True, verdict_with_records=True) == (RECORDS, True)
+    assert pick(use_other=True, records_ok=False, verdict=True, verdict_with_records=True) == (LEAPS, True)
+    # ... and one obtained with the plain groups (a bilinear camera was probed) the other way round
+    assert pick(use_other=True, records_ok=False, verdict=True, verdict_with_records=False) == (PLAIN, False)
+    assert pick(use_other=True, records_ok=True, verdict=True, verdict_with_records=False) == (LEAPS, False)
+    # HMRM_KERNEL=group / rec
+    for verdict in (False, True):
+        assert pick(forced=1, use_other=verdict, records_ok=True, verdict=verdict)[0] == PLAIN
+        assert pick(forced=3, records_ok=True, verdict=verdict)[0] == RECORDS
+        assert pick(forced=3, records_ok=False, verdict=verdict)[0] == PLAIN

@@ -753,6 +753,35 @@ def test_window_records_are_the_ninth_highest_and_the_cells_above_it(gpu):
                 assert all((x == 255) == (y == 255) for x, y in zip(r["xs"], r["ys"]))
 
 
+def test_window_records_follow_a_height_update(gpu, oracle):
+    """The records are built when the record kernel is first about to run after a height update (api.cpp ensure_records), not
+    by the update: frames before and after hmrm_scene_update -- other height range, other luminance weights -- equal the
+    oracle's under HMRM_KERNEL=rec, and the table read back afterwards describes the NEW thresholds."""
+    rng = np.random.RandomState(11)
+    mw, mh = 96, 80
+    v8 = np.where(rng.rand(mh, mw) < 1 / 40, 250, 30 + (rng.rand(mh, mw) * 8).astype(np.int64)).astype(np.uint8)
+    rgb = np.ascontiguousarray(np.stack([v8, np.roll(v8, 3, axis=1), np.roll(v8, 5, axis=0)], axis=2))
+    cmap = rng.randint(0, 256, size=(mh, mw, 4)).astype(np.uint8)
+    cam = gpu.Camera.make(width=120, height=68, projection=2, hfov=gpu.degrees_to_rads(150), hang=gpu.degrees_to_rads(-40.0),
+                          vang=gpu.degrees_to_rads(100), pos=(-10.0, 12.0, 9.0), step_dist=0.25, bg=(9, 8, 7))
+    p1 = gpu.SceneParams.make(0.0, 14.0, grid_width=1.0, lum=(1.0, 0.0, 0.0))
+    p2 = gpu.SceneParams.make(-2.0, 9.0, grid_width=1.0, lum=(0.0, 0.5, 0.5))
+    with kernel_variant("rec"):
+        scene = gpu.Scene(rgb, cmap, p1)
+        for params in (p1, p2, p1):
+            scene.update(params)
+            heights = oracle.update_heightmap(rgb, params)
+            ofb, total, capped, osteps, _ = oracle.render(oracle.make_cfg(cam, params, mw, mh), heights, cmap, per_pixel=True)
+            fb, st, steps, _ = scene.render_stats(cam, per_pixel=True)
+            assert capped == 0 and np.array_equal(fb, ofb) and np.array_equal(steps.astype(np.int64), osteps), params.max_height
+            assert np.array_equal(scene.render(cam), ofb) and st.leaps > 0
+            recs, thr = scene.read_records()
+            win = thr[0:16, 0:16]
+            ninth = np.sort(win.ravel())[::-1][8]
+            assert recs[0, 0]["max2"] >= ninth and recs[0, 0]["max2"] <= np.nextafter(np.float32(ninth), np.float32(np.inf))
+        scene.close()
+
+
 def test_record_kernel_on_sparse_tall_cells_fuzz(gpu, oracle):
     """The record kernel (HMRM_KERNEL=rec, frame.hpp WindowRecord: a 16-cell window's maximum without its 8 highest
     cells, and where those stand) on the maps it is for -- flat or gently rolling ground with tall single cells at a

@@ -12,5 +12,6 @@ for kind in ("smooth", "needles", "white"):
     scene = hmrm.Scene(rgb, cmap, hmrm.synth.WORKLOADS["C3"].scene_params())
     for _ in range(3):
         scene.update(hmrm.synth.WORKLOADS["C3"].scene_params())
+        scene.read_records()  # (the records are built on demand: api.cpp ensure_records)
     scene.close()
 print("done")
