@@ -87,3 +87,95 @@ def test_binade_boundaries_are_cell_boundaries_when_the_reciprocal_is_an_integer
                 assert near and ref_cell(v, gw) in (cell, cell - 1)
             cell, near = kernel(b + 1e-3 * gw, gw)
             assert not near and cell == ref_cell(b + 1e-3 * gw, gw) == int(b * inv)
+
+
+# ---- The exact-residual rule, worked out with rationals -------------------------------------------------
+#
+# Asked: replace the real division behind the guard by a residual.  With Q = RN(v / gw) (the reference's fdiv), v >= 0,
+# gw > 0 and an integer m >= 1 below 2^52 (m's significand is even, its predecessor's odd, so a tie rounds to m):
+#
+#     trunc(Q) >= m   <=>   v / gw >= m - h(m)   <=>   m * gw - v <= h(m) * gw        (all exact)
+#
+# where h(m) is half the gap between m and the double below it: 2^(e - 53) for 2^e < m < 2^(e + 1), 2^(e - 54) for m = 2^e.
+# In doubles: r = fma(m, gw, -v) is the correctly rounded residual, T = h(m) * gw is exact (a power of two times gw), and
+# rounding is monotone, so  r < T  proves  trunc(Q) >= m,  r > T  proves  trunc(Q) < m,  and only  r == T  is undecided.
+# The kernel's guard already narrows the reference's cell to {k, k - 1} (k = trunc(q'')); the residual at m = k decides.
+#
+# What the rule is worth: it replaces the DIVISION, which only a `near` position takes (2^-19 of the
+# positions: one wave-group in a thousand) -- it cannot replace the GUARD, because deciding a position with it costs
+# int -> double, fma, the exponent of k, a scaled gw, the power-of-two case and a compare against fract + compare of the
+# guard.  The multiplication and the guard are the 34 instructions per trip a general width costs; the rule removes none.
+
+
+def half_gap_below(m):
+    """h(m): half the distance from the integer m (as a double) to the double below it."""
+    assert 1 <= m < (1 << 52)
+    e = m.bit_length() - 1
+    return Fraction(2) ** (e - 54) if m & (m - 1) == 0 else Fraction(2) ** (e - 53)
+
+
+def residual_rule_exact(v, gw, m):
+    """trunc(RN(v / gw)) >= m, decided with rationals only."""
+    return Fraction(m) * Fraction(gw) - Fraction(v) <= half_gap_below(m) * Fraction(gw)
+
+
+def residual_rule_doubles(v, gw, m):
+    """The same from one fma and one exact scaling; None where the rounded residual equals the threshold."""
+    r = fma(float(m), gw, -v)
+    t = float(half_gap_below(m) * Fraction(gw))
+    assert Fraction(t) == half_gap_below(m) * Fraction(gw)  # (a power of two times gw: exact)
+    if r < t:
+        return True
+    if r > t:
+        return False
+    return None
+
+
+def check_residual(v, gw, counts):
+    cell, near = kernel(v, gw)
+    want = ref_cell(v, gw)
+    for m in (cell - 1, cell, cell + 1):
+        if m < 1:
+            continue
+        assert residual_rule_exact(v, gw, m) == (want >= m), (v, gw, m, want)
+        d = residual_rule_doubles(v, gw, m)
+        if d is None:
+            counts["undecided"] += 1
+        else:
+            assert d == (want >= m), (v, gw, m, want)
+    if near and cell >= 1:
+        # what the kernel would do with the rule: the guard says {cell, cell - 1}, the residual at m = cell picks one
+        d = residual_rule_doubles(v, gw, cell)
+        if d is not None:
+            assert (cell if d else cell - 1) == want
+            counts["near_decided"] += 1
+        else:
+            counts["near_undecided"] += 1
+
+
+def test_exact_residual_rule_decides_the_cell_without_a_division():
+    rng = random.Random(9)
+    counts = {"undecided": 0, "near_decided": 0, "near_undecided": 0}
+    for gw in GWS:
+        for _ in range(1500):
+            cells = rng.uniform(0.0, 5000.0)
+            check_residual(cells * gw * (1.0 + rng.uniform(-1e-9, 1e-9)), gw, counts)
+        for _ in range(150):
+            k = rng.randint(1, 1 << rng.randint(1, 24))
+            for e in range(-56, -17, 2):
+                for sign in (-1.0, 1.0):
+                    v = k * gw + sign * math.ldexp(rng.uniform(1.0, 2.0), e) * gw
+                    if v >= 0.0:
+                        check_residual(v, gw, counts)
+            # the rounding boundary itself and its neighbours: the doubles around (k - h(k)) * gw
+            b = float((Fraction(k) - half_gap_below(k)) * Fraction(gw))
+            for v in (math.nextafter(b, -math.inf), b, math.nextafter(b, math.inf)):
+                check_residual(v, gw, counts)
+            # powers of two: the gap below them is half the gap above
+            p = 1 << rng.randint(0, 24)
+            b = float((Fraction(p) - half_gap_below(p)) * Fraction(gw))
+            for v in (math.nextafter(b, -math.inf), b, math.nextafter(b, math.inf), p * gw):
+                check_residual(v, gw, counts)
+    assert counts["near_decided"] > 2000
+    # r == T needs the exact residual within half an ulp of T: it happens (only) on positions planted on the boundary
+    assert counts["near_undecided"] <= counts["near_decided"] // 10
