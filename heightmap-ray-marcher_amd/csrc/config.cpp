@@ -44,7 +44,7 @@ void height_scalar(Config &c, std::istream &in, const char *key, std::string *di
 // angles are given in degrees and kept in radians; the echo converts back (:367-384)
 template <auto Member>
 void angle(Config &c, std::istream &in, const char *key, std::string *) {
-	double deg;
+	double deg = 0.0; // (a key at the very end of a stream extracts nothing: the reference reads an uninitialised local there)
 	in >> deg;
 	c.*Member = degrees_to_rads(deg);
 	c.log << key << " " << rads_to_degrees(c.*Member) << "\n";
@@ -123,7 +123,7 @@ void position(Config &c, std::istream &in, const char *key, std::string *) {
 
 template <bool Normalise>
 void lum_weights(Config &c, std::istream &in, const char *, std::string *) {
-	double w[3];
+	double w[3] = {0.0, 0.0, 0.0};
 	in >> w[0] >> w[1] >> w[2];
 	const double total = Normalise ? w[0] + w[1] + w[2] : 1.0; // lum_norm divides by the sum (:417-427)
 	c.lum_r = Normalise ? w[0] / total : w[0];
@@ -134,7 +134,7 @@ void lum_weights(Config &c, std::istream &in, const char *, std::string *) {
 }
 
 void background(Config &c, std::istream &in, const char *key, std::string *) {
-	int v[3]; // read as ints, then narrowed (:456-461)
+	int v[3] = {0, 0, 0}; // read as ints, then narrowed (:456-461)
 	in >> v[0] >> v[1] >> v[2];
 	c.bg_r = (uint8_t)v[0];
 	c.bg_g = (uint8_t)v[1];

@@ -124,6 +124,21 @@ def test_malformed_number_ends_the_stream_like_iostream(hmrm, maps):
         cfg2.consume_string(f"hfov oops heightmap {hp} colormap {cp}")
 
 
+def test_a_key_at_the_very_end_of_a_stream_reads_zeros_not_garbage(hmrm, maps):
+    """`input >> x` at end of stream extracts nothing and leaves x alone: the reference's `bg_color`, `lum` and the angle
+    keys then use an uninitialised local (hmap.cpp:367-384, :417-427, :456-461).  The library's locals start at zero, so the
+    outcome is the one of a malformed number: defined, and the same on every run."""
+    hp, cp, *_ = maps
+    for _ in range(3):
+        cam = hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} bg_color 7 8 9 bg_color").camera()
+        assert (cam.bg_r, cam.bg_g, cam.bg_b) == (0, 0, 0)
+        cam = hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} hang 30 hang").camera()
+        assert cam.hang == 0.0
+        cfg = hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} lum 1 2")
+        p = cfg.scene_params()
+        assert (p.lum_r, p.lum_g, p.lum_b) == (1.0, 2.0, 0.0)
+
+
 def test_later_keys_win_and_streams_accumulate(hmrm, maps):
     hp, cp, *_ = maps
     cfg = hmrm.Config().consume_string(f"heightmap {hp} colormap {cp} step_dist 1 step_dist 2")
