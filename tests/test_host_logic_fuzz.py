@@ -15,7 +15,7 @@ def test_host_logic_survives_hostile_input_under_sanitizers(tmp_path):
     exe = str(tmp_path / "fuzz_host_logic")
     sources = ["config.cpp", "camera.cpp", "row_cost.cpp", "launch_order.cpp", "image_io.cpp", "jpeg_decode.cpp",
                "bmp_tga_decode.cpp", "legacy_formats.cpp"]
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fwrapv", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fwrapv", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=undefined,float-cast-overflow",
            "-I" + SRC, os.path.join(ROOT, "tests", "fuzz_host_logic.cpp")] + [os.path.join(SRC, s) for s in sources] + ["-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0 and "sanitize" in r.stderr:
