@@ -10,7 +10,7 @@ rounds=${1:-2}; shift
 WLS="${@:-C3 C2}"
 trap 'cp $P/_variants/libhmrm_A.so $P/libhmrm.so' EXIT
 for r in $(seq 1 $rounds); do
-  for v in A B G I; do
+  for v in ${SCHED_VARIANTS:-A B G I}; do
     cp $P/_variants/libhmrm_$v.so $P/libhmrm.so
     if [ "$r" = 1 ] && [ "$v" != A ]; then
       timeout -k 5 60 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -E "smoke|Error|error" | sed "s/^/variant $v: /"
