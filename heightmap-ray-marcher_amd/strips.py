@@ -151,6 +151,9 @@ class StripPipeline:
         self.blocks = [torch.zeros((self.vplan.world, rows, plan.width, 4), dtype=torch.uint8, device=device)
                        if (rotate_root or rank == 0) else None for _ in range(depth)]
         self.inflight = [None] * depth  # per slot: (frame index, root, [work handles], event or None)
+        # per slot, GPUs only: the reassembly of the slot's last frame (a copy out of `blocks[slot]`, enqueued on the stream
+        # collect() ran on) -- the next gather into that block waits for it, whichever stream the caller renders on
+        self.block_read = [None] * depth
         self.log = [] if keep_log else None  # (what, frame, chunk): the order things were issued in (tests only: it grows)
 
     def _note(self, what, k, c):
@@ -192,6 +195,8 @@ class StripPipeline:
                 ready = torch.cuda.Event()
                 ready.record(self.render_stream)
                 self.comm_stream.wait_event(ready)
+                if self.block_read[slot] is not None:
+                    self.comm_stream.wait_event(self.block_read[slot])
                 with torch.cuda.stream(self.comm_stream):
                     works.append(self.dist.gather(chunk, gather_list=dst, dst=root, async_op=True))
             elif self.dist is not None and world > 1:
@@ -222,6 +227,10 @@ class StripPipeline:
         # per virtual rank the reassembly's permute is the identity and its reshape a view, not a copy.)
         if frame.untyped_storage().data_ptr() == self.blocks[slot].untyped_storage().data_ptr():
             frame = frame.clone()
+        if self.comm_stream is not None:
+            done = self.torch.cuda.Event()
+            done.record()  # (the current stream: where the reassembly's copy was enqueued)
+            self.block_read[slot] = done
         return frame
 
     def run(self, frames, render_rows_of, on_frame=None):

@@ -277,3 +277,78 @@ def test_strip_pipeline_single_rank():
     assert seen == [True] * 5
     with pytest.raises(AssertionError):
         pipe.submit(0, render_rows_of(0)); pipe.submit(2, render_rows_of(2))  # frame 0 not collected: its buffers are still in use
+
+
+def test_strip_pipeline_stream_and_event_order_with_stand_in_streams():
+    """The branch StripPipeline takes on GPUs -- a render stream, a communication stream, events between them -- cannot run
+    here and has never run with more than one real rank; its control flow can: stand-ins for torch.cuda's Event / Stream /
+    stream() record what is recorded where and who waits for what.  Checked: every gather waits for its own render, a
+    gather into a block waits for the reassembly that last read that block (frame k - depth; whichever stream the caller
+    renders on), a buffer is only reused after its gather's event was synchronised, frames come out whole and in order."""
+    import types
+    import torch
+    strips = importlib.import_module("heightmap-ray-marcher_amd.strips")
+    log = []
+
+    class Event:
+        def record(self, stream=None):
+            log.append(("record", id(self), getattr(stream, "name", "current")))
+
+        def synchronize(self):
+            log.append(("sync", id(self)))
+
+    class Stream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_event(self, ev):
+            log.append(("wait", self.name, id(ev)))
+
+    class StreamGuard:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    class Work:
+        def wait(self):
+            log.append(("work.wait",))
+
+    class Gather:  # one rank: the gather is a copy into the root's list
+        def gather(self, t, gather_list=None, dst=0, async_op=False):
+            assert async_op and gather_list is not None and len(gather_list) == 1
+            log.append(("gather", dst))
+            gather_list[0].copy_(t)
+            return Work()
+
+    fake_torch = types.SimpleNamespace(zeros=torch.zeros, uint8=torch.uint8,
+                                       cuda=types.SimpleNamespace(Event=Event, stream=lambda s: StreamGuard()))
+    height, width, band, depth = 40, 6, 8, 2
+    plan = strips.BandPlan(height=height, width=width, band_rows=band, world=1)
+    pipe = strips.StripPipeline(plan, 0, Gather(), fake_torch, "cpu", depth=depth, chunks=1, rotate_root=True,
+                                render_stream=Stream("render"), comm_stream=Stream("comm"))
+
+    def render_rows_of(k):
+        def render_rows(strip, band_rows_, band_index, band_count):
+            log.append(("render", k))
+            strip.numpy()[:height] = _pattern_frame(k, height, width)
+        return render_rows
+    frames = {}
+    pipe.run(range(6), render_rows_of, on_frame=lambda k, f: frames.__setitem__(k, f.numpy().copy()))
+    assert all(np.array_equal(frames[k], _pattern_frame(k, height, width)) for k in range(6))
+
+    renders = [i for i, e in enumerate(log) if e[0] == "render"]
+    gathers = [i for i, e in enumerate(log) if e[0] == "gather"]
+    assert len(renders) == len(gathers) == 6
+    read_events = [e[1] for e in log if e[0] == "record" and e[2] == "current"]  # one per collected frame, in order
+    for k in range(6):
+        between = log[renders[k]:gathers[k]]
+        ready = [e[1] for e in between if e[0] == "record" and e[2] == "render"]
+        assert len(ready) == 1 and ("wait", "comm", ready[0]) in between  # the gather is behind its own render
+        if k >= depth:  # ... and behind the reassembly of the frame that used the block before
+            assert ("wait", "comm", read_events[k - depth]) in between
+        done = [e[1] for e in log[gathers[k]:] if e[0] == "record" and e[2] == "comm"][0]
+        synced = log.index(("sync", done))
+        if k + depth < 6:
+            assert synced < renders[k + depth]  # the strip buffer is rendered into again only after its gather is done
